@@ -1,0 +1,201 @@
+/*
+ * hw_mc.h -- C ABI of the MI355X-native Hull-White one-factor Monte Carlo engine (libhw_hip.so).
+ *
+ * This is the drop-in boundary for the reference's hot path
+ * (giulialionetti/Monte-Carlo-simulation-of-Hull-White-model-and-sensitivities-computation).
+ * The reference has no FFI/plugin interface: its three executables call CUDA kernels directly,
+ * with model constants in mutable __constant__ symbols and per-path cuRAND states in device
+ * memory.  Each entry point below names the reference call sequence it replaces (file:line,
+ * relative to the reference root).  Plain C types only: pointers, sizes, scalars.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative HW_E_* code; hw_last_error() gives the text
+ *     for the calling thread.  Nothing here calls exit() (the reference's check_cuda does,
+ *     include/common.cuh:114-120); the executables in src/ keep the reference's exit(1) behaviour.
+ *   - a context is bound to one GPU and one HIP stream; use one context per host thread.
+ *   - output buffers are caller-owned and need not be zeroed (the reference requires zeroed
+ *     accumulators, src/2_option_pricing.cu:122-126).
+ *   - random numbers: Philox4x32-10 in rocRAND's rocrand_state_philox4x32_10 layout,
+ *     key = seed, subsequence = global path id (path_offset + local index), offset 0, normals by
+ *     rocrand_normal4-style Box-Muller; time step i of a path uses component (i&3) of block (i>>2).
+ *     No RNG state lives in memory: "same seed" == common random numbers (the reference copies
+ *     48 MB of XORWOW states back and forth for that, src/3_sensitivity_analysis.cu:407-434).
+ *   - path counts are int64 and are processed exactly (no rounding up to a block multiple).
+ */
+#ifndef HW_MC_H
+#define HW_MC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HW_ABI_VERSION 1
+
+/* error codes */
+#define HW_OK            0
+#define HW_E_INVALID    -1   /* bad argument */
+#define HW_E_HIP        -2   /* HIP runtime error (text in hw_last_error) */
+#define HW_E_NO_MARKET  -3   /* hw_set_market not called ("Did you run Q1 first?") */
+#define HW_E_NOMEM      -4
+
+/* precision of the per-path stepper and payoff arithmetic */
+#define HW_F32 0
+#define HW_F64 1
+
+/* how the host builds the drift tables */
+#define HW_TABLES_F64      0  /* closed-form integrals evaluated in double                  */
+#define HW_TABLES_REF_F32  1  /* the reference's float32 host arithmetic, common.cuh:60-84   */
+
+/* which per-step arithmetic the ZBC kernel runs */
+#define HW_STEPPER_SUPERPOSED 0 /* r = m(t) +- s*y: deterministic mean path hoisted to the host,
+                                   one fma + one add per step and pair (default)              */
+#define HW_STEPPER_REFERENCE  1 /* the reference's evolve_hull_white_step verbatim on both legs
+                                   (fma + trapezoid per step, drift table read per step)      */
+
+/* drift table selection for a ZBC launch */
+#define HW_DRIFT_BASE     0  /* compute_drift_tables(sigma0), common.cuh:60-84                 */
+#define HW_DRIFT_SHIFTED  1  /* compute_shifted_drift_table(sigma, sigma0), 3_sens:374-398     */
+
+typedef struct hw_ctx hw_ctx;
+
+/* Replaces the compile-time configuration block include/common.cuh:16-39 and theta_func
+ * (common.cuh:228-230).  theta(t) = th_a1 + th_b1 t for t < th_break, th_a2 + th_b2 t after. */
+typedef struct hw_params {
+    double  a, sigma, r0, T_final;
+    int32_t n_steps, n_mat;
+    double  th_break, th_a1, th_b1, th_a2, th_b2;
+    int32_t precision;    /* HW_F32 | HW_F64 */
+    int32_t table_mode;   /* HW_TABLES_F64 | HW_TABLES_REF_F32 */
+} hw_params;
+
+/* One ZBC pricing launch == one call of simulate_ZBC_control_variate (common.cuh:286-409)
+ * preceded by init_rng (common.cuh:277-280) and followed by the five 4-byte D2H copies
+ * (src/2_option_pricing.cu:128-152). */
+typedef struct hw_zbc_request {
+    int64_t  n_pairs;       /* antithetic pairs == reference N_PATHS threads */
+    uint64_t seed;
+    uint64_t path_offset;   /* global id of this call's first pair (multi-GPU sharding) */
+    double   S1, S2, K;     /* option: exercise, bond maturity, strike */
+    double   sigma;         /* volatility for this launch; <= 0 means params.sigma */
+    int32_t  drift_mode;    /* HW_DRIFT_BASE | HW_DRIFT_SHIFTED (FD at sigma +- eps) */
+    int32_t  stepper;       /* HW_STEPPER_SUPERPOSED | HW_STEPPER_REFERENCE */
+} hw_zbc_request;
+
+typedef struct hw_device_info {
+    char    name[128];
+    int32_t device, compute_units, clock_mhz, wavefront_size;
+    int64_t lds_per_cu_bytes, hbm_bytes;
+} hw_device_info;
+
+/* kernel resource report: replaces the cudaFuncGetAttributes/occupancy printout of
+ * run_sensitivity_mc (src/3_sensitivity_analysis.cu:183-239). */
+typedef struct hw_kernel_info {
+    int32_t vgprs, sgprs, lds_bytes, scratch_bytes, max_threads_per_block;
+    int32_t block_size, blocks_per_cu;  /* occupancy for the launch geometry used */
+} hw_kernel_info;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+int         hw_abi_version(void);
+const char* hw_last_error(void);
+
+/* Reference defaults; profile "head" (theta intercept 0.019 as in the mounted source,
+ * common.cuh:76,229) or "readme" (0.014, the value behind every published number). */
+int  hw_default_params(hw_params* p, const char* profile);
+
+/* Replaces select_gpu() (common.cuh:122-141) + compute_constants() (common.cuh:92-110).
+ * device < 0 selects the device with the most free memory, as select_gpu does. */
+int  hw_create(const hw_params* p, int device, hw_ctx** out);
+void hw_destroy(hw_ctx* ctx);
+int  hw_get_device_info(hw_ctx* ctx, hw_device_info* out);
+int  hw_get_params(hw_ctx* ctx, hw_params* out);
+
+/* Replaces load_market_data_to_device (common.cuh:171-176).  P, f: n_mat float32 each
+ * (the data/P.bin, data/f.bin layout). */
+int  hw_set_market(hw_ctx* ctx, const float* P, const float* f, int32_t n_mat);
+
+/* Launch-geometry knobs: threads per block (64..1024, multiple of 64; 0 keeps the current),
+ * grid cap in workgroups per CU (0 = as many as 32 waves per CU hold), drift-table staging for
+ * the REFERENCE stepper (0 scalar loads, 1 LDS), pairs in flight per thread (1 or 2). */
+int  hw_set_launch(hw_ctx* ctx, int32_t block_size, int32_t max_blocks_per_cu, int32_t table_in_lds,
+                   int32_t pairs_in_flight);
+
+/* ---- hot path -------------------------------------------------------------------------- */
+/* out[5] = {sum X, sum Y, sum X^2, sum Y^2, sum XY} over 2*n_pairs samples (double).
+ * kernel_ms (may be NULL): hipEvent time of the launch(es), as 2_option:131-144 measures it. */
+int  hw_zbc_moments(hw_ctx* ctx, const hw_zbc_request* req, double out[5], float* kernel_ms);
+
+/* Same, enqueue only: results land in d_out (DEVICE pointer, 5 doubles) in stream order on
+ * `stream` (a hipStream_t; NULL = the context's stream).  No host synchronisation. */
+int  hw_zbc_moments_async(hw_ctx* ctx, const hw_zbc_request* req, double* d_out, void* stream);
+
+/* Up to 3 volatility scenarios priced from ONE pass over the same random numbers (common
+ * random numbers by construction).  Replaces the three kernel launches + state restores of
+ * run_finite_difference (3_sens:400-446): scenario k uses sigma[k] and drift_mode[k].
+ * out[n_scen*5].  SUPERPOSED stepper only. */
+int  hw_zbc_scenarios(hw_ctx* ctx, const hw_zbc_request* req, int32_t n_scen,
+                      const double* sigma, const int32_t* drift_mode,
+                      double* out, float* kernel_ms);
+
+/* Replaces init_rng + simulate_zcb (market_data.cuh:25-79): P_sum[n_mat] (double) of
+ * exp(-int r) over 2*n_pairs paths at every (n_steps/(n_mat-1))-th step; P_sum[0] = 2*n_pairs.
+ * sigma <= 0 means params.sigma. */
+int  hw_zcb_curve(hw_ctx* ctx, int64_t n_pairs, uint64_t seed, uint64_t path_offset,
+                  double sigma, double* P_sum, float* kernel_ms);
+int  hw_zcb_curve_async(hw_ctx* ctx, int64_t n_pairs, uint64_t seed, uint64_t path_offset,
+                        double sigma, double* d_P_sum, void* stream);
+
+/* Replaces init_rng + simulate_sensitivity (3_sens:22-96): out[0] = sum over n_paths of
+ * (term1 - term2); Vega = out[0] / n_paths.  antithetic = 0 reproduces the reference (one
+ * path per draw); 1 also evaluates the mirrored path (then Vega = out[0] / (2 n_paths)). */
+int  hw_vega_pathwise(hw_ctx* ctx, int64_t n_paths, uint64_t seed, uint64_t path_offset,
+                      double S1, double S2, double K, int32_t antithetic,
+                      double out[1], float* kernel_ms);
+int  hw_vega_pathwise_async(hw_ctx* ctx, int64_t n_paths, uint64_t seed, uint64_t path_offset,
+                            double S1, double S2, double K, int32_t antithetic,
+                            double* d_out, void* stream);
+
+/* Replaces simulate_paths_show (market_data.cuh:136-160): out[n][n_steps+1] float32 row-major. */
+int  hw_sample_paths(hw_ctx* ctx, int32_t n, uint64_t seed, uint64_t path_offset, float* out);
+
+/* The first `n_blocks` Philox blocks of subsequence `subseq` as normals, generated ON THE GPU
+ * (out[n_blocks*4]); lets tests pin the device RNG against rocRAND and the oracle. */
+int  hw_debug_normals(hw_ctx* ctx, uint64_t seed, uint64_t subseq, int32_t n_blocks, float* out);
+/* Same blocks as raw 32-bit Philox words (out[n_blocks*4]), bit-exact against rocrand4(). */
+int  hw_debug_raw(hw_ctx* ctx, uint64_t seed, uint64_t subseq, int32_t n_blocks, uint32_t* out);
+
+/* Per-launch kernel timing for benchmarks: after hw_profile_enable(ctx, n) each *_async / sync
+ * hot-path call records a hipEvent pair on its launch stream tightly around the PATH kernel
+ * (not the column reduction), for up to n launches.  hw_profile_read synchronises those events
+ * and writes the elapsed milliseconds (returns the count via *n_out) and disables profiling. */
+int  hw_profile_enable(hw_ctx* ctx, int32_t max_launches);
+int  hw_profile_read(hw_ctx* ctx, float* ms, int32_t cap, int32_t* n_out);
+
+int  hw_get_kernel_info(hw_ctx* ctx, const char* kernel /* "zbc" | "zbc_ref" | "zcb" | "vega" */,
+                        hw_kernel_info* out);
+
+/* ---- host-side pieces of the path (no GPU work) ----------------------------------------- */
+/* The tables the launch for (sigma, drift_mode) uses: compute_drift_tables / shifted table.
+ * drift, sigma_drift: n_steps doubles each (either may be NULL). */
+int  hw_drift_tables(hw_ctx* ctx, double sigma, int32_t drift_mode, double* drift, double* sigma_drift);
+
+/* compute_average_and_forward (market_data.cuh:101-127), float32 like the reference. */
+int  hw_average_and_forward(const hw_params* p, const double* P_sum, int64_t n_total,
+                            float* P, float* f);
+
+/* recover_theta (src/2_option_pricing.cu:14-35). */
+int  hw_recover_theta(const hw_params* p, const float* f, float* theta_rec, float* theta_orig, float* Ts);
+
+/* beta*, control-variate price (2_option:154-175, :277-281), evaluated in double.
+ * res[9] = {mean_X, mean_Y, var_Y, cov, beta, adjustment, price, var_X, rho} */
+int  hw_cv_price(const double sums[5], int64_t n_total, double P0S2, double res[9]);
+
+/* Exact Hull-White curve for the params' theta on the n_mat grid: P(0,T), f(0,T) as float32
+ * (synthetic market input that does not depend on a prior Monte Carlo run). */
+int  hw_analytic_curve(const hw_params* p, float* P, float* f);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HW_MC_H */

@@ -1,0 +1,843 @@
+// hw_engine.hip -- implementation of the C ABI in include/hw_mc.h on top of the gfx950 kernels
+// in hw_kernels.hpp.  Host work per launch: build the (sigma, drift-mode) tables and the mean
+// path in double (hw_model.hpp), pass a handful of scalars as kernel arguments, launch the
+// path kernel and the one-row-per-workgroup column reduction on the context's stream.
+//
+// There is NO CPU fallback in this library: every compute entry point launches HIP kernels
+// and fails with HW_E_HIP if the runtime or the GPU is unavailable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hw_mc.h"
+#include "hw_kernels.hpp"
+#include "hw_model.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(HW_E_HIP, "HIP error [%s] at %s:%d: %s", #expr, __FILE__, __LINE__, \
+                        hipGetErrorString(e_));                                           \
+    } while (0)
+
+constexpr double kLog2e = 1.4426950408889634074;
+
+}  // namespace
+
+struct hw_ctx {
+    hw_params p{};
+    int device = 0;
+    hipDeviceProp_t prop{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<float> P, f;
+    bool have_market = false;
+    // device workspaces
+    double* d_partials = nullptr;
+    size_t partials_cap = 0;          // doubles
+    double* d_out = nullptr;          // result staging, kOutCap doubles
+    double* d_scale = nullptr;        // per-column scale for the curve (n_mat doubles)
+    float* d_drift = nullptr;         // float table for the reference stepper / sample paths
+    // launch knobs
+    int block_size = 256;
+    int max_blocks_per_cu = 0;        // in units of block_size-thread workgroups; 0 = default
+    int table_in_lds = 0;
+    int ilp = 1;
+    // optional per-launch event pairs around the path kernel (hw_profile_enable)
+    std::vector<hipEvent_t> prof_ev;
+    int prof_used = 0, prof_cap = 0;
+};
+
+namespace {
+
+constexpr int kOutCap = 1024;
+
+int ensure_partials(hw_ctx* c, size_t doubles)
+{
+    if (doubles <= c->partials_cap) return HW_OK;
+    if (c->d_partials) HIP_TRY(hipFree(c->d_partials));
+    c->d_partials = nullptr;
+    c->partials_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_partials, doubles * sizeof(double)));
+    c->partials_cap = doubles;
+    return HW_OK;
+}
+
+struct Geometry {
+    int block, grid, iters;
+};
+
+// RAII-less helper: record the "before"/"after" event of the next profiled launch, if any.
+inline void prof_mark(hw_ctx* c, hipStream_t st, int which)
+{
+    if (c->prof_used >= c->prof_cap) return;
+    (void)hipEventRecord(c->prof_ev[2 * c->prof_used + which], st);
+    if (which == 1) c->prof_used++;
+}
+
+// One slot = one thread-iteration handling `ilp` units.  The grid is capped at the number of
+// workgroups the chip holds at once (32 waves per CU) times `max_blocks_per_cu` override; the
+// remainder is walked by the per-thread `iters` loop.
+Geometry geometry(const hw_ctx* c, int64_t n_units, int ilp)
+{
+    Geometry g{};
+    g.block = c->block_size;
+    const int64_t per_block = (int64_t)g.block * ilp;
+    int64_t want = (n_units + per_block - 1) / per_block;
+    if (want < 1) want = 1;
+    const int waves_per_block = g.block / 64;
+    int per_cu = c->max_blocks_per_cu > 0 ? c->max_blocks_per_cu : std::max(1, 32 / waves_per_block);
+    const int64_t cap = (int64_t)c->prop.multiProcessorCount * per_cu;
+    g.grid = (int)std::min<int64_t>(want, cap);
+    const int64_t per_iter = (int64_t)g.grid * per_block;
+    g.iters = (int)((n_units + per_iter - 1) / per_iter);
+    if (g.iters < 1) g.iters = 1;
+    return g;
+}
+
+struct Scenario {
+    double sigma;
+    int drift_mode;
+    hw::StepConstants k;
+    std::vector<double> drift;
+    double m_n, cI_n;   // mean short rate and mean integral at S1
+    double A, B;
+};
+
+int build_scenario(hw_ctx* c, double sigma, int drift_mode, int n_steps_S1, double S1, double S2,
+                   Scenario* s)
+{
+    if (!(sigma > 0.0)) sigma = c->p.sigma;
+    if (drift_mode != HW_DRIFT_BASE && drift_mode != HW_DRIFT_SHIFTED)
+        return fail(HW_E_INVALID, "drift_mode must be HW_DRIFT_BASE or HW_DRIFT_SHIFTED");
+    s->sigma = sigma;
+    s->drift_mode = drift_mode;
+    s->k = hw::step_constants(c->p, sigma);
+    if (drift_mode == HW_DRIFT_SHIFTED)
+        hw::shifted_drift_table(c->p, sigma, c->p.sigma, &s->drift);
+    else
+        hw::drift_tables(c->p, c->p.sigma, &s->drift, nullptr);   // fitted at the base sigma
+    std::vector<double> m, cI;
+    hw::mean_path(c->p.r0, s->k.e, s->k.dt, s->drift, n_steps_S1, &m, &cI);
+    s->m_n = m[n_steps_S1];
+    s->cI_n = cI[n_steps_S1];
+    hw::bond_AB(c->p, sigma, c->P, c->f, S1, S2, &s->A, &s->B);
+    return HW_OK;
+}
+
+template <typename REAL>
+hwk::ZbcScen<REAL> make_scen(const Scenario& s, double K)
+{
+    hwk::ZbcScen<REAL> z;
+    z.cz = (REAL)(s.k.dt * s.k.sig_st * kLog2e);
+    z.cw = (REAL)(s.B * s.k.sig_st * kLog2e);
+    z.D0 = (REAL)std::exp(-s.cI_n);
+    z.P0 = (REAL)(s.A * std::exp(-s.B * s.m_n));
+    z.K = (REAL)K;
+    return z;
+}
+
+int check_request(hw_ctx* c, const hw_zbc_request* r, int* n_steps_S1)
+{
+    if (!c || !r) return fail(HW_E_INVALID, "null context or request");
+    if (!c->have_market) return fail(HW_E_NO_MARKET, "market curves not set (hw_set_market): did you run Q1 first?");
+    if (r->n_pairs < 0) return fail(HW_E_INVALID, "n_pairs < 0");
+    if (!(r->S1 > 0.0) || !(r->S2 > r->S1) || r->S2 > c->p.T_final + 1e-9)
+        return fail(HW_E_INVALID, "need 0 < S1 < S2 <= T_final");
+    const int n = hw::steps_to(c->p, r->S1);
+    if (n < 1 || n > c->p.n_steps) return fail(HW_E_INVALID, "S1 maps to %d steps (grid has %d)", n, c->p.n_steps);
+    *n_steps_S1 = n;
+    return HW_OK;
+}
+
+template <typename REAL, int NSCEN>
+int launch_zbc_superposed(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, const Scenario* sc,
+                          double* d_out, hipStream_t st)
+{
+    const int ilp = c->ilp;
+    const Geometry g = geometry(c, r->n_pairs, ilp);
+    int rc = ensure_partials(c, (size_t)g.grid * 5 * NSCEN);
+    if (rc) return rc;
+    hwk::ZbcArgs<REAL, NSCEN> a{};
+    a.n_pairs = r->n_pairs;
+    a.seed = r->seed;
+    a.path_offset = r->path_offset;
+    a.n_steps = n_steps_S1;
+    a.iters = g.iters;
+    a.e = (REAL)sc[0].k.e;
+    for (int k = 0; k < NSCEN; k++) a.sc[k] = make_scen<REAL>(sc[k], r->K);
+    prof_mark(c, st, 0);
+    if (ilp == 2)
+        hipLaunchKernelGGL((hwk::zbc_superposed_kernel<REAL, NSCEN, 2>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials);
+    else
+        hipLaunchKernelGGL((hwk::zbc_superposed_kernel<REAL, NSCEN, 1>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials);
+    prof_mark(c, st, 1);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(5 * NSCEN), dim3(256), 0, st,
+                       (const double*)c->d_partials, g.grid, 5 * NSCEN, (const double*)nullptr, -1.0, d_out);
+    HIP_TRY(hipGetLastError());
+    return HW_OK;
+}
+
+int launch_zbc_reference(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, const Scenario& s,
+                         double* d_out, hipStream_t st)
+{
+    const Geometry g = geometry(c, r->n_pairs, 1);
+    int rc = ensure_partials(c, (size_t)g.grid * 5);
+    if (rc) return rc;
+    std::vector<float> tab(n_steps_S1);
+    for (int i = 0; i < n_steps_S1; i++) tab[i] = (float)s.drift[i];
+    HIP_TRY(hipMemcpyAsync(c->d_drift, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    hwk::ZbcRefArgs a{};
+    a.n_pairs = r->n_pairs;
+    a.seed = r->seed;
+    a.path_offset = r->path_offset;
+    a.n_steps = n_steps_S1;
+    a.iters = g.iters;
+    a.r0 = (float)c->p.r0;
+    a.e = (float)s.k.e;
+    a.dt = (float)s.k.dt;
+    a.sig_st = (float)s.k.sig_st;
+    a.A = (float)s.A;
+    a.B = (float)s.B;
+    a.K = (float)r->K;
+    prof_mark(c, st, 0);
+    if (c->table_in_lds)
+        hipLaunchKernelGGL(hwk::zbc_reference_kernel<1>, dim3(g.grid), dim3(g.block),
+                           (size_t)n_steps_S1 * sizeof(float), st, a, (const float*)c->d_drift, c->d_partials);
+    else
+        hipLaunchKernelGGL(hwk::zbc_reference_kernel<0>, dim3(g.grid), dim3(g.block), 0, st, a,
+                           (const float*)c->d_drift, c->d_partials);
+    prof_mark(c, st, 1);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(5), dim3(256), 0, st, (const double*)c->d_partials,
+                       g.grid, 5, (const double*)nullptr, -1.0, d_out);
+    HIP_TRY(hipGetLastError());
+    return HW_OK;
+}
+
+int zbc_enqueue(hw_ctx* c, const hw_zbc_request* r, int n_scen, const double* sigma,
+                const int32_t* drift_mode, double* d_out, hipStream_t st)
+{
+    int n_steps_S1 = 0;
+    int rc = check_request(c, r, &n_steps_S1);
+    if (rc) return rc;
+    if (n_scen < 1 || n_scen > hwk::kMaxScen) return fail(HW_E_INVALID, "n_scen must be 1..%d", hwk::kMaxScen);
+    Scenario sc[hwk::kMaxScen];
+    for (int k = 0; k < n_scen; k++) {
+        rc = build_scenario(c, sigma ? sigma[k] : r->sigma, drift_mode ? drift_mode[k] : r->drift_mode,
+                            n_steps_S1, r->S1, r->S2, &sc[k]);
+        if (rc) return rc;
+    }
+    if (r->stepper == HW_STEPPER_REFERENCE) {
+        if (n_scen != 1) return fail(HW_E_INVALID, "the REFERENCE stepper prices one scenario per launch");
+        if (c->p.precision != HW_F32) return fail(HW_E_INVALID, "the REFERENCE stepper is float32 only");
+        return launch_zbc_reference(c, r, n_steps_S1, sc[0], d_out, st);
+    }
+    if (r->stepper != HW_STEPPER_SUPERPOSED) return fail(HW_E_INVALID, "unknown stepper %d", r->stepper);
+    const bool f64 = c->p.precision == HW_F64;
+    switch (n_scen) {
+        case 1: return f64 ? launch_zbc_superposed<double, 1>(c, r, n_steps_S1, sc, d_out, st)
+                           : launch_zbc_superposed<float, 1>(c, r, n_steps_S1, sc, d_out, st);
+        case 2: return f64 ? launch_zbc_superposed<double, 2>(c, r, n_steps_S1, sc, d_out, st)
+                           : launch_zbc_superposed<float, 2>(c, r, n_steps_S1, sc, d_out, st);
+        default: return f64 ? launch_zbc_superposed<double, 3>(c, r, n_steps_S1, sc, d_out, st)
+                            : launch_zbc_superposed<float, 3>(c, r, n_steps_S1, sc, d_out, st);
+    }
+}
+
+template <typename REAL>
+int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, double sigma,
+               double* d_P_sum, hipStream_t st)
+{
+    const hw_params& p = c->p;
+    if (!(sigma > 0.0)) sigma = p.sigma;
+    const int n_mat = p.n_mat, stride = p.n_steps / (n_mat - 1);
+    const hw::StepConstants k = hw::step_constants(p, sigma);
+    std::vector<double> drift, m, cI;
+    hw::drift_tables(p, sigma, &drift, nullptr);          // recompute_market_data, 3_sens:449-455
+    hw::mean_path(p.r0, k.e, k.dt, drift, p.n_steps, &m, &cI);
+    std::vector<double> scale(n_mat, 1.0);
+    for (int j = 1; j < n_mat; j++) scale[j] = std::exp(-cI[(size_t)j * stride]);
+    HIP_TRY(hipMemcpyAsync(c->d_scale, scale.data(), n_mat * sizeof(double), hipMemcpyHostToDevice, st));
+
+    const Geometry g = geometry(c, n_pairs, 1);
+    int rc = ensure_partials(c, (size_t)g.grid * n_mat);
+    if (rc) return rc;
+    hwk::ZcbArgs<REAL> a{};
+    a.n_pairs = n_pairs;
+    a.seed = seed;
+    a.path_offset = path_offset;
+    a.n_steps = p.n_steps;
+    a.n_mat = n_mat;
+    a.stride = stride;
+    a.iters = g.iters;
+    a.e = (REAL)k.e;
+    a.cz = (REAL)(k.dt * k.sig_st * kLog2e);
+    const size_t lds = (size_t)(g.block / 64) * n_mat * sizeof(double);
+    prof_mark(c, st, 0);
+    hipLaunchKernelGGL(hwk::zcb_curve_kernel<REAL>, dim3(g.grid), dim3(g.block), lds, st, a, c->d_partials);
+    prof_mark(c, st, 1);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(n_mat), dim3(256), 0, st, (const double*)c->d_partials,
+                       g.grid, n_mat, (const double*)c->d_scale, 2.0 * (double)n_pairs, d_P_sum);
+    HIP_TRY(hipGetLastError());
+    return HW_OK;
+}
+
+template <typename REAL>
+int launch_vega(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset, double S1, double S2,
+                double K, int antithetic, int n_steps_S1, double* d_out, hipStream_t st)
+{
+    const hw_params& p = c->p;
+    Scenario s;
+    int rc = build_scenario(c, p.sigma, HW_DRIFT_BASE, n_steps_S1, S1, S2, &s);
+    if (rc) return rc;
+    std::vector<double> sdrift, D, cD;
+    hw::drift_tables(p, p.sigma, nullptr, &sdrift);
+    hw::mean_path(0.0, s.k.e, s.k.dt, sdrift, n_steps_S1, &D, &cD);       // 3_sens:41,44,58-61
+
+    const int ilp = c->ilp;
+    const Geometry g = geometry(c, n_paths, ilp);
+    rc = ensure_partials(c, (size_t)g.grid);
+    if (rc) return rc;
+    hwk::VegaArgs<REAL> a{};
+    a.n_paths = n_paths;
+    a.seed = seed;
+    a.path_offset = path_offset;
+    a.n_steps = n_steps_S1;
+    a.iters = g.iters;
+    a.antithetic = antithetic ? 1 : 0;
+    a.e = (REAL)s.k.e;
+    const hwk::ZbcScen<REAL> z = make_scen<REAL>(s, K);
+    a.cz = z.cz; a.cw = z.cw; a.D0 = z.D0; a.P0 = z.P0; a.K = z.K;
+    a.B = (REAL)s.B;
+    a.gB = (REAL)(p.sigma / (2.0 * p.a) * (-std::expm1(-2.0 * p.a * S1)) * s.B);
+    a.Dn = (REAL)D[n_steps_S1];
+    a.cD = (REAL)cD[n_steps_S1];
+    a.s_over_sigma = (REAL)(s.k.sig_st / p.sigma);
+    a.zs = (REAL)(s.k.dt * s.k.sig_st / p.sigma);
+    prof_mark(c, st, 0);
+    if (ilp == 2)
+        hipLaunchKernelGGL((hwk::vega_pathwise_kernel<REAL, 2>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials);
+    else
+        hipLaunchKernelGGL((hwk::vega_pathwise_kernel<REAL, 1>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials);
+    prof_mark(c, st, 1);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(1), dim3(256), 0, st, (const double*)c->d_partials,
+                       g.grid, 1, (const double*)nullptr, -1.0, d_out);
+    HIP_TRY(hipGetLastError());
+    return HW_OK;
+}
+
+// run `enqueue(d_out, stream)` on the context stream between events, copy n doubles back
+template <typename F>
+int timed_sync(hw_ctx* c, int n_out, double* out, float* kernel_ms, F enqueue)
+{
+    if (n_out > kOutCap) return fail(HW_E_INVALID, "too many outputs");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    int rc = enqueue(c->d_out, c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipMemcpyAsync(out, c->d_out, n_out * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, c->ev0, c->ev1));
+    return HW_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================
+extern "C" {
+
+int hw_abi_version(void) { return HW_ABI_VERSION; }
+
+const char* hw_last_error(void) { return g_err.c_str(); }
+
+int hw_default_params(hw_params* p, const char* profile)
+{
+    if (!p) return fail(HW_E_INVALID, "null params");
+    p->a = 1.0; p->sigma = 0.1; p->r0 = 0.012; p->T_final = 10.0;       // common.cuh:22,37-39
+    p->n_steps = 1000; p->n_mat = 101;                                  // common.cuh:17,21
+    p->th_break = 5.0; p->th_a1 = 0.012; p->th_b1 = 0.0014; p->th_b2 = 0.001;
+    p->precision = HW_F32;
+    p->table_mode = HW_TABLES_F64;
+    if (!profile || !strcmp(profile, "head")) p->th_a2 = 0.019;         // common.cuh:76,229
+    else if (!strcmp(profile, "readme")) p->th_a2 = 0.014;              // 3_sens:387; README numbers
+    else return fail(HW_E_INVALID, "unknown theta profile '%s' (head|readme)", profile);
+    return HW_OK;
+}
+
+static int validate_params(const hw_params* p)
+{
+    if (!p) return fail(HW_E_INVALID, "null params");
+    if (!(p->a > 0) || !(p->sigma > 0) || !(p->T_final > 0)) return fail(HW_E_INVALID, "a, sigma, T_final must be > 0");
+    if (p->n_steps < 1 || p->n_steps > (1 << 24)) return fail(HW_E_INVALID, "n_steps out of range");
+    if (p->n_mat < 2) return fail(HW_E_INVALID, "n_mat < 2");
+    if (p->n_steps % (p->n_mat - 1) != 0)                               // common.cuh:25-27
+        return fail(HW_E_INVALID, "n_steps must be evenly divisible by (n_mat - 1)");
+    if (p->precision != HW_F32 && p->precision != HW_F64) return fail(HW_E_INVALID, "bad precision");
+    if (p->table_mode != HW_TABLES_F64 && p->table_mode != HW_TABLES_REF_F32) return fail(HW_E_INVALID, "bad table_mode");
+    return HW_OK;
+}
+
+int hw_create(const hw_params* p, int device, hw_ctx** out)
+{
+    if (!out) return fail(HW_E_INVALID, "null out");
+    *out = nullptr;
+    int rc = validate_params(p);
+    if (rc) return rc;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (count < 1) return fail(HW_E_HIP, "no HIP device visible");
+    if (device < 0) {                                                    // select_gpu, common.cuh:122-141
+        size_t best_free = 0;
+        device = 0;
+        for (int i = 0; i < count; i++) {
+            size_t fr = 0, tot = 0;
+            if (hipSetDevice(i) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess && fr > best_free) {
+                best_free = fr;
+                device = i;
+            }
+        }
+    }
+    if (device >= count) return fail(HW_E_INVALID, "device %d out of range (%d visible)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    hw_ctx* c = new (std::nothrow) hw_ctx();
+    if (!c) return fail(HW_E_NOMEM, "out of host memory");
+    c->p = *p;
+    c->device = device;
+    hipError_t e = hipGetDeviceProperties(&c->prop, device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipMalloc(&c->d_out, kOutCap * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&c->d_scale, (size_t)p->n_mat * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&c->d_drift, (size_t)p->n_steps * sizeof(float));
+    if (e != hipSuccess) {
+        hw_destroy(c);
+        return fail(HW_E_HIP, "hw_create: %s", hipGetErrorString(e));
+    }
+    if (c->prop.warpSize != 64) {
+        hw_destroy(c);
+        return fail(HW_E_HIP, "device wavefront size is %d; this library is built for wave64 gfx950", c->prop.warpSize);
+    }
+    *out = c;
+    return HW_OK;
+}
+
+void hw_destroy(hw_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_partials) (void)hipFree(c->d_partials);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_scale) (void)hipFree(c->d_scale);
+    if (c->d_drift) (void)hipFree(c->d_drift);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t ev : c->prof_ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int hw_get_device_info(hw_ctx* c, hw_device_info* out)
+{
+    if (!c || !out) return fail(HW_E_INVALID, "null argument");
+    memset(out, 0, sizeof *out);
+    snprintf(out->name, sizeof out->name, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+    out->device = c->device;
+    out->compute_units = c->prop.multiProcessorCount;
+    out->clock_mhz = c->prop.clockRate / 1000;
+    out->wavefront_size = c->prop.warpSize;
+    out->lds_per_cu_bytes = (int64_t)c->prop.maxSharedMemoryPerMultiProcessor;
+    out->hbm_bytes = (int64_t)c->prop.totalGlobalMem;
+    return HW_OK;
+}
+
+int hw_get_params(hw_ctx* c, hw_params* out)
+{
+    if (!c || !out) return fail(HW_E_INVALID, "null argument");
+    *out = c->p;
+    return HW_OK;
+}
+
+int hw_set_market(hw_ctx* c, const float* P, const float* f, int32_t n_mat)
+{
+    if (!c || !P || !f) return fail(HW_E_INVALID, "null argument");
+    if (n_mat != c->p.n_mat) return fail(HW_E_INVALID, "Expected %d floats, got %d", c->p.n_mat, n_mat);
+    for (int i = 0; i < n_mat; i++)
+        if (!(P[i] > 0.0f) || !std::isfinite(P[i]) || !std::isfinite(f[i]))
+            return fail(HW_E_INVALID, "market curve has a non-positive or non-finite entry at %d", i);
+    c->P.assign(P, P + n_mat);
+    c->f.assign(f, f + n_mat);
+    c->have_market = true;
+    return HW_OK;
+}
+
+int hw_set_launch(hw_ctx* c, int32_t block_size, int32_t max_blocks_per_cu, int32_t table_in_lds,
+                  int32_t pairs_in_flight)
+{
+    if (!c) return fail(HW_E_INVALID, "null context");
+    if (block_size) {
+        if (block_size < 64 || block_size > 1024 || block_size % 64) return fail(HW_E_INVALID, "block_size must be a multiple of 64 in [64,1024]");
+        c->block_size = block_size;
+    }
+    if (max_blocks_per_cu < 0) return fail(HW_E_INVALID, "max_blocks_per_cu < 0");
+    if (pairs_in_flight != 0 && pairs_in_flight != 1 && pairs_in_flight != 2)
+        return fail(HW_E_INVALID, "pairs_in_flight must be 1 or 2");
+    c->max_blocks_per_cu = max_blocks_per_cu;
+    if (pairs_in_flight) c->ilp = pairs_in_flight;
+    c->table_in_lds = table_in_lds ? 1 : 0;
+    return HW_OK;
+}
+
+// ---- ZBC ----------------------------------------------------------------------------------
+int hw_zbc_moments(hw_ctx* c, const hw_zbc_request* r, double out[5], float* kernel_ms)
+{
+    if (!c || !r || !out) return fail(HW_E_INVALID, "null argument");
+    return timed_sync(c, 5, out, kernel_ms, [&](double* d_out, hipStream_t st) {
+        return zbc_enqueue(c, r, 1, nullptr, nullptr, d_out, st);
+    });
+}
+
+int hw_zbc_moments_async(hw_ctx* c, const hw_zbc_request* r, double* d_out, void* stream)
+{
+    if (!c || !r || !d_out) return fail(HW_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    return zbc_enqueue(c, r, 1, nullptr, nullptr, d_out, stream ? (hipStream_t)stream : c->stream);
+}
+
+int hw_zbc_scenarios(hw_ctx* c, const hw_zbc_request* r, int32_t n_scen, const double* sigma,
+                     const int32_t* drift_mode, double* out, float* kernel_ms)
+{
+    if (!c || !r || !out || !sigma || !drift_mode) return fail(HW_E_INVALID, "null argument");
+    if (n_scen < 1 || n_scen > hwk::kMaxScen) return fail(HW_E_INVALID, "n_scen must be 1..%d", hwk::kMaxScen);
+    return timed_sync(c, 5 * n_scen, out, kernel_ms, [&](double* d_out, hipStream_t st) {
+        return zbc_enqueue(c, r, n_scen, sigma, drift_mode, d_out, st);
+    });
+}
+
+// ---- curve --------------------------------------------------------------------------------
+static int zcb_enqueue(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, double sigma,
+                       double* d_P_sum, hipStream_t st)
+{
+    if (n_pairs < 0) return fail(HW_E_INVALID, "n_pairs < 0");
+    return c->p.precision == HW_F64 ? launch_zcb<double>(c, n_pairs, seed, path_offset, sigma, d_P_sum, st)
+                                    : launch_zcb<float>(c, n_pairs, seed, path_offset, sigma, d_P_sum, st);
+}
+
+int hw_zcb_curve(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, double sigma,
+                 double* P_sum, float* kernel_ms)
+{
+    if (!c || !P_sum) return fail(HW_E_INVALID, "null argument");
+    return timed_sync(c, c->p.n_mat, P_sum, kernel_ms, [&](double* d_out, hipStream_t st) {
+        return zcb_enqueue(c, n_pairs, seed, path_offset, sigma, d_out, st);
+    });
+}
+
+int hw_zcb_curve_async(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, double sigma,
+                       double* d_P_sum, void* stream)
+{
+    if (!c || !d_P_sum) return fail(HW_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    return zcb_enqueue(c, n_pairs, seed, path_offset, sigma, d_P_sum, stream ? (hipStream_t)stream : c->stream);
+}
+
+// ---- Vega ---------------------------------------------------------------------------------
+static int vega_enqueue(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset, double S1,
+                        double S2, double K, int antithetic, double* d_out, hipStream_t st)
+{
+    hw_zbc_request r{};
+    r.n_pairs = n_paths; r.S1 = S1; r.S2 = S2; r.K = K;
+    int n_steps_S1 = 0;
+    int rc = check_request(c, &r, &n_steps_S1);
+    if (rc) return rc;
+    return c->p.precision == HW_F64
+               ? launch_vega<double>(c, n_paths, seed, path_offset, S1, S2, K, antithetic, n_steps_S1, d_out, st)
+               : launch_vega<float>(c, n_paths, seed, path_offset, S1, S2, K, antithetic, n_steps_S1, d_out, st);
+}
+
+int hw_vega_pathwise(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset, double S1,
+                     double S2, double K, int32_t antithetic, double out[1], float* kernel_ms)
+{
+    if (!c || !out) return fail(HW_E_INVALID, "null argument");
+    return timed_sync(c, 1, out, kernel_ms, [&](double* d_out, hipStream_t st) {
+        return vega_enqueue(c, n_paths, seed, path_offset, S1, S2, K, antithetic, d_out, st);
+    });
+}
+
+int hw_vega_pathwise_async(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset, double S1,
+                           double S2, double K, int32_t antithetic, double* d_out, void* stream)
+{
+    if (!c || !d_out) return fail(HW_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    return vega_enqueue(c, n_paths, seed, path_offset, S1, S2, K, antithetic, d_out,
+                        stream ? (hipStream_t)stream : c->stream);
+}
+
+// ---- small kernels ------------------------------------------------------------------------
+int hw_sample_paths(hw_ctx* c, int32_t n, uint64_t seed, uint64_t path_offset, float* out)
+{
+    if (!c || !out) return fail(HW_E_INVALID, "null argument");
+    if (n < 0 || n > (1 << 20)) return fail(HW_E_INVALID, "n out of range");
+    if (n == 0) return HW_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const hw_params& p = c->p;
+    const hw::StepConstants k = hw::step_constants(p, p.sigma);
+    std::vector<double> drift;
+    hw::drift_tables(p, p.sigma, &drift, nullptr);
+    std::vector<float> tab(p.n_steps);
+    for (int i = 0; i < p.n_steps; i++) tab[i] = (float)drift[i];
+    const size_t bytes = (size_t)n * (p.n_steps + 1) * sizeof(float);
+    float* d_paths = nullptr;
+    HIP_TRY(hipMalloc(&d_paths, bytes));
+    hipError_t e = hipMemcpyAsync(c->d_drift, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(hwk::sample_paths_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, d_paths,
+                           (const float*)c->d_drift, n, p.n_steps, seed, path_offset, (float)p.r0, (float)k.e,
+                           (float)k.sig_st);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_paths, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_paths);
+    if (e != hipSuccess) return fail(HW_E_HIP, "hw_sample_paths: %s", hipGetErrorString(e));
+    return HW_OK;
+}
+
+int hw_debug_normals(hw_ctx* c, uint64_t seed, uint64_t subseq, int32_t n_blocks, float* out)
+{
+    if (!c || !out) return fail(HW_E_INVALID, "null argument");
+    if (n_blocks < 1 || n_blocks > (1 << 20)) return fail(HW_E_INVALID, "n_blocks out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    float* d_n = nullptr;
+    uint32_t* d_raw = nullptr;
+    HIP_TRY(hipMalloc(&d_n, (size_t)n_blocks * 4 * sizeof(float)));
+    hipError_t e = hipMalloc(&d_raw, (size_t)n_blocks * 8 * sizeof(uint32_t));
+    std::vector<uint32_t> raw((size_t)n_blocks * 8);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(hwk::debug_normals_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, c->stream, d_n, d_raw,
+                           seed, subseq, n_blocks);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_n, (size_t)n_blocks * 4 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(raw.data(), d_raw, raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_n);
+    if (d_raw) (void)hipFree(d_raw);
+    if (e != hipSuccess) return fail(HW_E_HIP, "hw_debug_normals: %s", hipGetErrorString(e));
+    for (int j = 0; j < n_blocks; j++)
+        for (int w = 0; w < 4; w++)
+            if (raw[8 * j + w] != raw[8 * j + 4 + w])
+                return fail(HW_E_HIP, "device Philox self-check failed: hoisted and plain rounds differ at block %d", j);
+    return HW_OK;
+}
+
+int hw_debug_raw(hw_ctx* c, uint64_t seed, uint64_t subseq, int32_t n_blocks, uint32_t* out)
+{
+    if (!c || !out) return fail(HW_E_INVALID, "null argument");
+    if (n_blocks < 1 || n_blocks > (1 << 20)) return fail(HW_E_INVALID, "n_blocks out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    float* d_n = nullptr;
+    uint32_t* d_raw = nullptr;
+    HIP_TRY(hipMalloc(&d_n, (size_t)n_blocks * 4 * sizeof(float)));
+    hipError_t e = hipMalloc(&d_raw, (size_t)n_blocks * 8 * sizeof(uint32_t));
+    std::vector<uint32_t> raw((size_t)n_blocks * 8);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(hwk::debug_normals_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, c->stream, d_n, d_raw,
+                           seed, subseq, n_blocks);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(raw.data(), d_raw, raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_n);
+    if (d_raw) (void)hipFree(d_raw);
+    if (e != hipSuccess) return fail(HW_E_HIP, "hw_debug_raw: %s", hipGetErrorString(e));
+    for (int j = 0; j < n_blocks; j++)
+        for (int w = 0; w < 4; w++) out[4 * j + w] = raw[8 * j + w];
+    return HW_OK;
+}
+
+int hw_profile_enable(hw_ctx* c, int32_t max_launches)
+{
+    if (!c) return fail(HW_E_INVALID, "null context");
+    if (max_launches < 0 || max_launches > 100000) return fail(HW_E_INVALID, "max_launches out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    while ((int)c->prof_ev.size() < 2 * max_launches) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev));
+        c->prof_ev.push_back(ev);
+    }
+    c->prof_used = 0;
+    c->prof_cap = max_launches;
+    return HW_OK;
+}
+
+int hw_profile_read(hw_ctx* c, float* ms, int32_t cap, int32_t* n_out)
+{
+    if (!c || !ms || !n_out) return fail(HW_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const int n = std::min(c->prof_used, (int)cap);
+    for (int i = 0; i < n; i++) {
+        HIP_TRY(hipEventSynchronize(c->prof_ev[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms[i], c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+    }
+    *n_out = n;
+    c->prof_cap = 0;
+    c->prof_used = 0;
+    return HW_OK;
+}
+
+int hw_get_kernel_info(hw_ctx* c, const char* kernel, hw_kernel_info* out)
+{
+    if (!c || !kernel || !out) return fail(HW_E_INVALID, "null argument");
+    const void* fn = nullptr;
+    const bool f64 = c->p.precision == HW_F64;
+    if (!strcmp(kernel, "zbc"))
+        fn = f64 ? (const void*)hwk::zbc_superposed_kernel<double, 1, 1> : (const void*)hwk::zbc_superposed_kernel<float, 1, 1>;
+    else if (!strcmp(kernel, "zbc_ref"))
+        fn = c->table_in_lds ? (const void*)hwk::zbc_reference_kernel<1> : (const void*)hwk::zbc_reference_kernel<0>;
+    else if (!strcmp(kernel, "zcb"))
+        fn = f64 ? (const void*)hwk::zcb_curve_kernel<double> : (const void*)hwk::zcb_curve_kernel<float>;
+    else if (!strcmp(kernel, "vega"))
+        fn = f64 ? (const void*)hwk::vega_pathwise_kernel<double, 1> : (const void*)hwk::vega_pathwise_kernel<float, 1>;
+    else
+        return fail(HW_E_INVALID, "unknown kernel '%s'", kernel);
+    HIP_TRY(hipSetDevice(c->device));
+    hipFuncAttributes attr{};
+    HIP_TRY(hipFuncGetAttributes(&attr, fn));
+    memset(out, 0, sizeof *out);
+    out->vgprs = attr.numRegs;
+    out->sgprs = 0;
+    out->lds_bytes = (int32_t)attr.sharedSizeBytes;
+    out->scratch_bytes = (int32_t)attr.localSizeBytes;
+    out->max_threads_per_block = attr.maxThreadsPerBlock;
+    out->block_size = c->block_size;
+    int nb = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, c->block_size, 0));
+    out->blocks_per_cu = nb;
+    return HW_OK;
+}
+
+// ---- host-side pieces ----------------------------------------------------------------------
+int hw_drift_tables(hw_ctx* c, double sigma, int32_t drift_mode, double* drift, double* sigma_drift)
+{
+    if (!c) return fail(HW_E_INVALID, "null context");
+    if (!(sigma > 0.0)) sigma = c->p.sigma;
+    std::vector<double> d, sd;
+    if (drift_mode == HW_DRIFT_SHIFTED) {
+        hw::shifted_drift_table(c->p, sigma, c->p.sigma, &d);
+        hw::drift_tables(c->p, sigma, nullptr, &sd);
+    } else if (drift_mode == HW_DRIFT_BASE) {
+        hw::drift_tables(c->p, sigma, &d, &sd);
+    } else {
+        return fail(HW_E_INVALID, "bad drift_mode");
+    }
+    if (drift) std::copy(d.begin(), d.end(), drift);
+    if (sigma_drift) std::copy(sd.begin(), sd.end(), sigma_drift);
+    return HW_OK;
+}
+
+int hw_average_and_forward(const hw_params* p, const double* P_sum, int64_t n_total, float* P, float* f)
+{
+    int rc = validate_params(p);
+    if (rc) return rc;
+    if (!P_sum || !P || !f || n_total < 1) return fail(HW_E_INVALID, "bad argument");
+    {
+#pragma clang fp contract(off)
+    const int n_mat = p->n_mat;
+    const float inv_dT = 1 / ((float)p->T_final / (float)(n_mat - 1));              // 1_bond:76
+    for (int j = 0; j < n_mat; j++) P[j] = (float)(P_sum[j] / (double)n_total);     // market_data.cuh:114
+    for (int j = 0; j < n_mat; j++) {
+        const int lo = (j == 0) ? 0 : j - 1;                                        // market_data.cuh:122-125
+        const int hi = (j == n_mat - 1) ? n_mat - 1 : j + 1;
+        const float scale = (j == 0 || j == n_mat - 1) ? 1.0f : 0.5f;
+        f[j] = -scale * inv_dT * (logf(P[hi]) - logf(P[lo]));
+    }
+    }
+    return HW_OK;
+}
+
+int hw_recover_theta(const hw_params* p, const float* f, float* theta_rec, float* theta_orig, float* Ts)
+{
+    int rc = validate_params(p);
+    if (rc) return rc;
+    if (!f || !theta_rec || !theta_orig || !Ts) return fail(HW_E_INVALID, "null argument");
+    {
+#pragma clang fp contract(off)
+    const int n = p->n_mat;
+    const float a = (float)p->a, sg = (float)p->sigma;
+    const float spacing = (float)p->T_final / (float)(n - 1);
+    for (int i = 0; i < n; i++) {
+        const float T = (float)i * spacing;                                         // 2_option:25
+        float d;
+        if (i == 0) d = (f[1] - f[0]) / spacing;                                    // common.cuh:250-258
+        else if (i == n - 1) d = (f[i] - f[i - 1]) / spacing;
+        else d = (f[i + 1] - f[i - 1]) / (2.0f * spacing);
+        const float convexity = (sg * sg / (2.0f * a)) * (1.0f - expf(-2.0f * a * T)); // 2_option:28-29
+        theta_rec[i] = d + a * f[i] + convexity;                                    // 2_option:31
+        theta_orig[i] = (T < (float)p->th_break) ? ((float)p->th_a1 + (float)p->th_b1 * T)
+                                                 : ((float)p->th_a2 + (float)p->th_b2 * T);
+        Ts[i] = T;
+    }
+    }
+    return HW_OK;
+}
+
+int hw_cv_price(const double sums[5], int64_t n_total, double P0S2, double res[9])
+{
+    if (!sums || !res || n_total < 1) return fail(HW_E_INVALID, "bad argument");
+    const double N = (double)n_total;
+    const double mX = sums[0] / N, mY = sums[1] / N;                                // 2_option:157-158
+    const double varY = sums[3] / N - mY * mY;                                      // 2_option:161-163
+    const double cov = sums[4] / N - mX * mY;                                       // 2_option:166-168
+    const double beta = cov / varY;                                                 // 2_option:171
+    const double adj = beta * (mY - P0S2);                                          // 2_option:174
+    const double varX = sums[2] / N - mX * mX;                                      // 2_option:277-278
+    res[0] = mX; res[1] = mY; res[2] = varY; res[3] = cov; res[4] = beta; res[5] = adj;
+    res[6] = mX - adj;                                                              // 2_option:175
+    res[7] = varX;
+    res[8] = cov / std::sqrt(varX * varY);                                          // 2_option:281
+    return HW_OK;
+}
+
+int hw_analytic_curve(const hw_params* p, float* P, float* f)
+{
+    int rc = validate_params(p);
+    if (rc) return rc;
+    if (!P || !f) return fail(HW_E_INVALID, "null argument");
+    const double spacing = p->T_final / (p->n_mat - 1);
+    for (int j = 0; j < p->n_mat; j++) {
+        double Pv, fv;
+        hw::analytic_curve(*p, j * spacing, &Pv, &fv);
+        P[j] = (float)Pv;
+        f[j] = (float)fv;
+    }
+    return HW_OK;
+}
+
+}  // extern "C"

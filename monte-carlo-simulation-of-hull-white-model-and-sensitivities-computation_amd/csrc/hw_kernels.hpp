@@ -1,0 +1,573 @@
+// hw_kernels.hpp -- hand-written HIP kernels for gfx950 (MI355X, CDNA4, wave64).
+//
+// One thread walks one antithetic pair (ZBC, curve) or one path (Vega).  Nothing is read from
+// HBM inside the time loop: the Philox4x32-10 counter is built in registers from
+// (seed, global path id, step block), and the only global traffic of a launch is one small
+// row of double partial sums per workgroup.  The kernels are VALU-issue-bound (integer
+// multiplies of Philox + the four transcendentals of Box-Muller), not HBM-bound; see DESIGN.md.
+//
+// Reference kernels these replace (paths relative to the reference root):
+//   zbc_superposed_kernel / zbc_reference_kernel : simulate_ZBC_control_variate, include/common.cuh:286-409
+//   zcb_curve_kernel                             : simulate_zcb, include/market_data.cuh:25-79
+//   vega_pathwise_kernel                         : simulate_sensitivity, src/3_sensitivity_analysis.cu:22-96
+//   sample_paths_kernel                          : simulate_paths_show, include/market_data.cuh:136-160
+//   (init_rng, include/common.cuh:277-280, has no counterpart: there is no RNG state to initialise)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hwk {
+
+constexpr int kWave = 64;          // gfx950 wavefront
+constexpr int kMaxWaves = 16;      // 1024-thread workgroup
+constexpr int kMaxScen = 3;
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10, rocRAND counter layout: counter = {block j, 0, path lo, path hi}, key = seed.
+// The ten round keys depend only on the seed (wave-uniform -> SGPRs).  Because counter words
+// 0/1 are wave-uniform and words 2/3 are constant along a path, round 1 and half of rounds 2-3
+// are loop-invariant per lane: philox_path() hoists them, philox_block() spends 17 wide
+// multiplies and 34 xors per block instead of 20 and 40.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kM0 = 0xD2511F53u, kM1 = 0xCD9E8D57u, kW0 = 0x9E3779B9u, kW1 = 0xBB67AE85u;
+
+struct PhiloxKey {
+    uint32_t k0[10], k1[10];
+};
+
+__device__ __forceinline__ PhiloxKey philox_key(uint64_t seed)
+{
+    PhiloxKey k;
+    uint32_t a = (uint32_t)seed, b = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        k.k0[r] = a;
+        k.k1[r] = b;
+        a += kW0;
+        b += kW1;
+    }
+    return k;
+}
+
+__device__ __forceinline__ void mulhilo(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo)
+{
+    const uint64_t p = (uint64_t)a * (uint64_t)b;   // one v_mad_u64_u32
+    hi = (uint32_t)(p >> 32);
+    lo = (uint32_t)p;
+}
+
+struct PhiloxPath {       // per-lane loop invariants of one subsequence
+    uint32_t A2, Q, R, L0, T;
+};
+
+__device__ __forceinline__ PhiloxPath philox_path(const PhiloxKey& k, uint64_t pid)
+{
+    const uint32_t plo = (uint32_t)pid, phi = (uint32_t)(pid >> 32);
+    uint32_t hi1, lo1, H0, L0;
+    mulhilo(kM1, plo, hi1, lo1);                    // round 1, word-2 product
+    const uint32_t c0 = hi1 ^ k.k0[0];              // (counter word 1 is 0)
+    mulhilo(kM0, c0, H0, L0);                       // round 2, word-0 product
+    PhiloxPath pp;
+    pp.A2 = phi ^ k.k1[0];
+    pp.Q = lo1 ^ k.k0[1];
+    pp.R = H0 ^ k.k1[1];
+    pp.L0 = L0;
+    pp.T = L0 ^ k.k1[2];
+    return pp;
+}
+
+// Block j (wave-uniform) of the path: the four 32-bit outputs of rocrand4().
+__device__ __forceinline__ void philox_block(const PhiloxKey& k, const PhiloxPath& pp, uint32_t j,
+                                             uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
+{
+    uint32_t hi0, lo0, hi1, lo1;
+    mulhilo(kM0, j, hi0, lo0);                      // round 1 (scalar: j is uniform)
+    uint32_t c2 = pp.A2 ^ hi0;
+    uint32_t c3 = lo0;
+    mulhilo(kM1, c2, hi1, lo1);                     // round 2
+    uint32_t c0 = hi1 ^ pp.Q;
+    uint32_t c1 = lo1;
+    c2 = pp.R ^ c3;
+    mulhilo(kM0, c0, hi0, lo0);                     // round 3
+    mulhilo(kM1, c2, hi1, lo1);
+    c0 = hi1 ^ c1 ^ k.k0[2];
+    c1 = lo1;
+    c2 = hi0 ^ pp.T;
+    c3 = lo0;
+#pragma unroll
+    for (int r = 3; r < 10; r++) {                  // rounds 4..10
+        mulhilo(kM0, c0, hi0, lo0);
+        mulhilo(kM1, c2, hi1, lo1);
+        c0 = hi1 ^ c1 ^ k.k0[r];
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k.k1[r];
+        c3 = lo0;
+    }
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+
+// Reference (unhoisted) form, used by the debug kernel to cross-check the hoisting.
+__device__ __forceinline__ void philox_block_plain(uint64_t seed, uint64_t pid, uint64_t j, uint32_t* o)
+{
+    uint32_t c0 = (uint32_t)j, c1 = (uint32_t)(j >> 32), c2 = (uint32_t)pid, c3 = (uint32_t)(pid >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0, lo0, hi1, lo1;
+        mulhilo(kM0, c0, hi0, lo0);
+        mulhilo(kM1, c2, hi1, lo1);
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += kW0; k1 += kW1;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// Box-Muller as rocrand_normal.h:53-68, on the hardware transcendentals:
+//   u = 2^-32 + x 2^-32 in (0,1];  s = sqrt(-2 ln u) = v_sqrt(v_log(u) * -2 ln 2)
+//   angle = 2 pi (2^-32 + y 2^-32); v_sin_f32 / v_cos_f32 take the angle in revolutions.
+__device__ __forceinline__ void box_muller(uint32_t x, uint32_t y, float& n0, float& n1)
+{
+    constexpr float kInv = 2.3283064e-10f;          // ROCRAND_2POW32_INV
+    const float u = __builtin_fmaf((float)x, kInv, kInv);
+    const float w = __builtin_fmaf((float)y, kInv, kInv);
+    const float s = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u) * -1.3862943611198906f);
+    n0 = __builtin_amdgcn_sinf(w) * s;
+    n1 = __builtin_amdgcn_cosf(w) * s;
+}
+
+__device__ __forceinline__ void normal4(const PhiloxKey& k, const PhiloxPath& pp, uint32_t j, float (&g)[4])
+{
+    uint32_t w0, w1, w2, w3;
+    philox_block(k, pp, j, w0, w1, w2, w3);
+    box_muller(w0, w1, g[0], g[1]);
+    box_muller(w2, w3, g[2], g[3]);
+}
+
+// ------------------------------------------------------------------------------------------
+// small math helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float  hw_exp2(float x)  { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ double hw_exp2(double x) { return exp2(x); }
+__device__ __forceinline__ float  hw_fma(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double hw_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float  hw_max0(float a)  { return fmaxf(a, 0.0f); }
+__device__ __forceinline__ double hw_max0(double a) { return fmax(a, 0.0); }
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+// Workgroup sum of N doubles per thread -> out[0..N) (one row of the partials buffer).
+// Fixed summation order (lane tree, then waves in index order): bit-reproducible.
+template <int N>
+__device__ __forceinline__ void block_sum_store(double (&v)[N], double* smem /*[kMaxWaves*N]*/, double* out)
+{
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int nwaves = (blockDim.x + kWave - 1) >> 6;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const double s = wave_sum(v[k]);
+        if (lane == 0) smem[wave * N + k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        double t = 0.0;
+        for (int w = 0; w < nwaves; w++) t += smem[w * N + threadIdx.x];
+        out[threadIdx.x] = t;
+    }
+}
+
+// Second (tiny) launch: out[k] = scale[k] * sum_b partials[b*ncol + k], fixed order.
+// grid = ncol workgroups of 256 threads.  fix0: if >= 0, out[0] is overwritten with that value
+// (P_sum[0] = 2 N of market_data.cuh:76-78, done without the reference's write race).
+__global__ void finalize_columns_kernel(const double* __restrict__ partials, int nrows, int ncol,
+                                        const double* __restrict__ scale, double fix0,
+                                        double* __restrict__ out)
+{
+    __shared__ double smem[256];
+    const int k = blockIdx.x;
+    double t = 0.0;
+    for (int b = threadIdx.x; b < nrows; b += blockDim.x) t += partials[(size_t)b * ncol + k];
+    smem[threadIdx.x] = t;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if (threadIdx.x < s) smem[threadIdx.x] += smem[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double r = smem[0];
+        if (scale) r *= scale[k];
+        if (k == 0 && fix0 >= 0.0) r = fix0;
+        out[k] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The shared inner loop: y_{i+1} = e y_i + G_i,  S += y_{i+1}   (one fma + one add per step).
+// r_i = m_i +- s y_i and int r = cI +- dt s (S - y/2) are reconstructed in the epilogues from
+// host-computed m_n, cI_n (hw_model.hpp, mean_path).
+// ------------------------------------------------------------------------------------------
+template <typename REAL, int ILP>
+__device__ __forceinline__ void ou_walk(const PhiloxKey& key, const PhiloxPath (&pp)[ILP], int n_steps,
+                                        REAL e, REAL (&y)[ILP], REAL (&S)[ILP])
+{
+    const int nblk = n_steps >> 2;
+    for (int j = 0; j < nblk; j++) {
+#pragma unroll
+        for (int q = 0; q < ILP; q++) {
+            float g[4];
+            normal4(key, pp[q], (uint32_t)j, g);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                y[q] = hw_fma(y[q], e, (REAL)g[c]);
+                S[q] += y[q];
+            }
+        }
+    }
+    const int rem = n_steps & 3;
+    if (rem) {                                        // wave-uniform tail
+#pragma unroll
+        for (int q = 0; q < ILP; q++) {
+            float g[4];
+            normal4(key, pp[q], (uint32_t)nblk, g);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                if (c < rem) {
+                    y[q] = hw_fma(y[q], e, (REAL)g[c]);
+                    S[q] += y[q];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// ZBC control-variate moments, superposed stepper.
+// ------------------------------------------------------------------------------------------
+template <typename REAL>
+struct ZbcScen {
+    REAL cz;   // dt * s * log2(e)          : exp(-+z),  z = dt s (S - y/2)
+    REAL cw;   // B * s * log2(e)           : exp(-+w),  w = B s y
+    REAL D0;   // exp(-cI_n)                : discount of the mean path
+    REAL P0;   // A exp(-B m_n)             : bond price on the mean path
+    REAL K;
+};
+
+template <typename REAL, int NSCEN>
+struct ZbcArgs {
+    int64_t n_pairs;
+    uint64_t seed, path_offset;
+    int32_t n_steps, iters;
+    REAL e;
+    ZbcScen<REAL> sc[NSCEN];
+};
+
+template <typename REAL, int NSCEN, int ILP>
+__global__ void __launch_bounds__(1024)
+zbc_superposed_kernel(const ZbcArgs<REAL, NSCEN> a, double* __restrict__ partials)
+{
+    __shared__ double smem[kMaxWaves * 5 * NSCEN];
+    const PhiloxKey key = philox_key(a.seed);
+    const int64_t T = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+
+    double acc[5 * NSCEN];
+#pragma unroll
+    for (int k = 0; k < 5 * NSCEN; k++) acc[k] = 0.0;
+
+    for (int it = 0; it < a.iters; it++) {
+        PhiloxPath pp[ILP];
+        bool valid[ILP];
+        REAL y[ILP], S[ILP];
+#pragma unroll
+        for (int q = 0; q < ILP; q++) {
+            int64_t p = t + ((int64_t)it * ILP + q) * T;
+            valid[q] = p < a.n_pairs;
+            if (!valid[q]) p = 0;
+            pp[q] = philox_path(key, a.path_offset + (uint64_t)p);
+            y[q] = 0;
+            S[q] = 0;
+        }
+        ou_walk<REAL, ILP>(key, pp, a.n_steps, a.e, y, S);
+#pragma unroll
+        for (int q = 0; q < ILP; q++) {
+            const REAL h = S[q] - (REAL)0.5 * y[q];
+#pragma unroll
+            for (int k = 0; k < NSCEN; k++) {
+                const ZbcScen<REAL>& sc = a.sc[k];
+                const REAL z = sc.cz * h, w = sc.cw * y[q];
+                const REAL d1 = sc.D0 * hw_exp2(-z), d2 = sc.D0 * hw_exp2(z);     // common.cuh:342-343
+                const REAL P1 = sc.P0 * hw_exp2(-w), P2 = sc.P0 * hw_exp2(w);     // common.cuh:337-338
+                const REAL c1 = d1 * P1, c2 = d2 * P2;                            // common.cuh:347-348
+                const REAL x1 = d1 * hw_max0(P1 - sc.K), x2 = d2 * hw_max0(P2 - sc.K); // :352-353
+                if (valid[q]) {
+                    acc[5 * k + 0] += (double)(x1 + x2);                          // common.cuh:356-362
+                    acc[5 * k + 1] += (double)(c1 + c2);
+                    acc[5 * k + 2] += (double)(x1 * x1 + x2 * x2);
+                    acc[5 * k + 3] += (double)(c1 * c1 + c2 * c2);
+                    acc[5 * k + 4] += (double)(x1 * c1 + x2 * c2);
+                }
+            }
+        }
+    }
+    block_sum_store<5 * NSCEN>(acc, smem, partials + (size_t)blockIdx.x * 5 * NSCEN);
+}
+
+// ------------------------------------------------------------------------------------------
+// ZBC control-variate moments, REFERENCE stepper: evolve_hull_white_step (common.cuh:237-244)
+// verbatim on both legs, drift table read every step (scalar loads, or LDS when TABLE_LDS).
+// float32 only (it exists to restate the reference's arithmetic on the GPU).
+// ------------------------------------------------------------------------------------------
+struct ZbcRefArgs {
+    int64_t n_pairs;
+    uint64_t seed, path_offset;
+    int32_t n_steps, iters;
+    float r0, e, dt, sig_st, A, B, K;
+};
+
+template <int TABLE_LDS>
+__global__ void __launch_bounds__(1024)
+zbc_reference_kernel(const ZbcRefArgs a, const float* __restrict__ drift, double* __restrict__ partials)
+{
+    __shared__ double smem[kMaxWaves * 5];
+    extern __shared__ float s_drift[];
+    const float* tab = drift;
+    if (TABLE_LDS) {
+        for (int i = threadIdx.x; i < a.n_steps; i += blockDim.x) s_drift[i] = drift[i];
+        __syncthreads();
+        tab = s_drift;
+    }
+    const PhiloxKey key = philox_key(a.seed);
+    const int64_t T = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr float kLog2e = 1.4426950408889634f;
+
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (int it = 0; it < a.iters; it++) {
+        int64_t p = t + (int64_t)it * T;
+        const bool valid = p < a.n_pairs;
+        if (!valid) p = 0;
+        const PhiloxPath pp = philox_path(key, a.path_offset + (uint64_t)p);
+        float r1 = a.r0, r2 = a.r0, I1 = 0.0f, I2 = 0.0f;           // common.cuh:318-319
+        for (int i = 0; i < a.n_steps; i += 4) {                     // common.cuh:325-332
+            float g[4];
+            normal4(key, pp, (uint32_t)(i >> 2), g);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (i + c < a.n_steps) {
+                    const float d = tab[i + c];
+                    const float sG = a.sig_st * g[c];
+                    const float r1n = __builtin_fmaf(r1, a.e, d + sG);   // common.cuh:241
+                    I1 += 0.5f * (r1 + r1n) * a.dt;                       // common.cuh:242
+                    r1 = r1n;
+                    const float r2n = __builtin_fmaf(r2, a.e, d - sG);
+                    I2 += 0.5f * (r2 + r2n) * a.dt;
+                    r2 = r2n;
+                }
+            }
+        }
+        const float P1 = a.A * hw_exp2(-a.B * r1 * kLog2e);            // common.cuh:337-338
+        const float P2 = a.A * hw_exp2(-a.B * r2 * kLog2e);
+        const float d1 = hw_exp2(-I1 * kLog2e), d2 = hw_exp2(-I2 * kLog2e);  // common.cuh:342-343
+        const float c1 = d1 * P1, c2 = d2 * P2;
+        const float x1 = d1 * fmaxf(P1 - a.K, 0.0f), x2 = d2 * fmaxf(P2 - a.K, 0.0f);
+        if (valid) {
+            acc[0] += (double)(x1 + x2);
+            acc[1] += (double)(c1 + c2);
+            acc[2] += (double)(x1 * x1 + x2 * x2);
+            acc[3] += (double)(c1 * c1 + c2 * c2);
+            acc[4] += (double)(x1 * c1 + x2 * c2);
+        }
+    }
+    block_sum_store<5>(acc, smem, partials + (size_t)blockIdx.x * 5);
+}
+
+// ------------------------------------------------------------------------------------------
+// Zero-coupon curve: every `stride` steps add exp(-I1)+exp(-I2) = D0_m (2^{z'} + 2^{-z'}) to
+// maturity m.  The lane-invariant factor D0_m is applied in double by finalize_columns_kernel.
+// Per-wave running sums live in LDS as doubles: row [wave][n_mat], touched by lane 0 only.
+// ------------------------------------------------------------------------------------------
+template <typename REAL>
+struct ZcbArgs {
+    int64_t n_pairs;
+    uint64_t seed, path_offset;
+    int32_t n_steps, n_mat, stride, iters;
+    REAL e;
+    REAL cz;   // dt * s * log2(e)
+};
+
+template <typename REAL>
+__global__ void __launch_bounds__(1024)
+zcb_curve_kernel(const ZcbArgs<REAL> a, double* __restrict__ partials)
+{
+    extern __shared__ double s_rows[];                 // [nwaves][n_mat]
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int nwaves = (blockDim.x + kWave - 1) >> 6;
+    for (int i = threadIdx.x; i < nwaves * a.n_mat; i += blockDim.x) s_rows[i] = 0.0;
+    __syncthreads();
+    double* row = s_rows + wave * a.n_mat;
+
+    const PhiloxKey key = philox_key(a.seed);
+    const int64_t T = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+
+    for (int it = 0; it < a.iters; it++) {
+        int64_t p = t + (int64_t)it * T;
+        const bool valid = p < a.n_pairs;
+        if (!valid) p = 0;
+        const PhiloxPath pp = philox_path(key, a.path_offset + (uint64_t)p);
+        REAL y = 0, S = 0;
+        int countdown = a.stride, m = 0;
+        for (int i = 0; i < a.n_steps; i += 4) {
+            float g[4];
+            normal4(key, pp, (uint32_t)(i >> 2), g);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (i + c < a.n_steps) {                                   // wave-uniform
+                    y = hw_fma(y, a.e, (REAL)g[c]);
+                    S += y;
+                    if (--countdown == 0) {                                // market_data.cuh:57
+                        countdown = a.stride;
+                        m++;
+                        if (m < a.n_mat) {                                 // market_data.cuh:59
+                            const REAL z = a.cz * (S - (REAL)0.5 * y);
+                            REAL q = hw_exp2(z) + hw_exp2(-z);             // market_data.cuh:60
+                            if (!valid) q = 0;
+                            const REAL qs = wave_sum(q);                   // market_data.cuh:61
+                            if (lane == 0) row[m] += (double)qs;           // market_data.cuh:62-64
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < a.n_mat; k += blockDim.x) {
+        double tsum = 0.0;
+        for (int w = 0; w < nwaves; w++) tsum += s_rows[w * a.n_mat + k];
+        partials[(size_t)blockIdx.x * a.n_mat + k] = tsum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pathwise Vega: d_sigma r follows the same OU recursion with its own drift and shock
+// (s/sigma) G (3_sens:54-61), so  d_sigma r_i = D_i + (s/sigma) y_i  with the SAME y.
+// ------------------------------------------------------------------------------------------
+template <typename REAL>
+struct VegaArgs {
+    int64_t n_paths;
+    uint64_t seed, path_offset;
+    int32_t n_steps, iters, antithetic;
+    REAL e;
+    REAL cz, cw, D0, P0, K;   // as ZbcScen
+    REAL B;                   // B(S1,S2)
+    REAL gB;                  // sigma/(2a) (1 - e^{-2 a S1}) B      (3_sens:16-18)
+    REAL Dn;                  // mean of d_sigma r at S1
+    REAL cD;                  // mean of int d_sigma r
+    REAL s_over_sigma;        // s / sigma
+    REAL zs;                  // dt * s / sigma : stochastic part of int d_sigma r = zs (S - y/2)
+};
+
+template <typename REAL>
+__device__ __forceinline__ REAL vega_leg(const VegaArgs<REAL>& a, REAL y, REAL h)
+{
+    const REAL z = a.cz * h, w = a.cw * y;
+    const REAL Pv = a.P0 * hw_exp2(-w);                                    // 3_sens:65
+    const REAL disc = a.D0 * hw_exp2(-z);                                  // 3_sens:68
+    const REAL dsr = a.Dn + a.s_over_sigma * y;
+    const REAL int_dsr = a.cD + a.zs * h;
+    const REAL dP = -Pv * a.B * (a.gB + dsr);                              // 3_sens:15-19
+    const REAL term1 = (Pv > a.K) ? dP * disc : (REAL)0;                   // 3_sens:72-74
+    const REAL term2 = int_dsr * disc * hw_max0(Pv - a.K);                 // 3_sens:77-78
+    return term1 - term2;                                                  // 3_sens:80
+}
+
+template <typename REAL, int ILP>
+__global__ void __launch_bounds__(1024)
+vega_pathwise_kernel(const VegaArgs<REAL> a, double* __restrict__ partials)
+{
+    __shared__ double smem[kMaxWaves];
+    const PhiloxKey key = philox_key(a.seed);
+    const int64_t T = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double acc[1] = {0.0};
+    for (int it = 0; it < a.iters; it++) {
+        PhiloxPath pp[ILP];
+        bool valid[ILP];
+        REAL y[ILP], S[ILP];
+#pragma unroll
+        for (int q = 0; q < ILP; q++) {
+            int64_t p = t + ((int64_t)it * ILP + q) * T;
+            valid[q] = p < a.n_paths;
+            if (!valid[q]) p = 0;
+            pp[q] = philox_path(key, a.path_offset + (uint64_t)p);
+            y[q] = 0;
+            S[q] = 0;
+        }
+        ou_walk<REAL, ILP>(key, pp, a.n_steps, a.e, y, S);
+#pragma unroll
+        for (int q = 0; q < ILP; q++) {
+            const REAL h = S[q] - (REAL)0.5 * y[q];
+            REAL v = vega_leg<REAL>(a, y[q], h);
+            if (a.antithetic) v += vega_leg<REAL>(a, -y[q], -h);
+            if (valid[q]) acc[0] += (double)v;
+        }
+    }
+    block_sum_store<1>(acc, smem, partials + blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// Sample trajectories for plotting (reference arithmetic, one thread per path, tiny).
+// ------------------------------------------------------------------------------------------
+__global__ void sample_paths_kernel(float* __restrict__ out, const float* __restrict__ drift, int n,
+                                    int n_steps, uint64_t seed, uint64_t path_offset, float r0,
+                                    float e, float sig_st)
+{
+    const int pid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= n) return;
+    const PhiloxKey key = philox_key(seed);
+    const PhiloxPath pp = philox_path(key, path_offset + (uint64_t)pid);
+    float* row = out + (size_t)pid * (size_t)(n_steps + 1);
+    float r = r0;
+    row[0] = r;                                                            // market_data.cuh:148
+    for (int i = 0; i < n_steps; i += 4) {
+        float g[4];
+        normal4(key, pp, (uint32_t)(i >> 2), g);
+        for (int c = 0; c < 4 && i + c < n_steps; c++) {
+            r = __builtin_fmaf(r, e, drift[i + c] + sig_st * g[c]);        // common.cuh:241
+            row[i + c + 1] = r;                                            // market_data.cuh:157
+        }
+    }
+}
+
+// Device RNG probe: normals (hoisted Philox) of one subsequence, plus the raw words of every
+// block computed twice -- raw[8j..8j+3] by the hoisted form the kernels use, raw[8j+4..8j+7] by
+// the plain ten-round form -- so a test can pin both against the oracle / rocRAND.
+__global__ void debug_normals_kernel(float* __restrict__ out, uint32_t* __restrict__ raw, uint64_t seed,
+                                     uint64_t subseq, int n_blocks)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_blocks) return;
+    const PhiloxKey key = philox_key(seed);
+    const PhiloxPath pp = philox_path(key, subseq);
+    float g[4];
+    normal4(key, pp, (uint32_t)j, g);
+    for (int c = 0; c < 4; c++) out[4 * j + c] = g[c];
+    uint32_t o[4], h0, h1, h2, h3;
+    philox_block(key, pp, (uint32_t)j, h0, h1, h2, h3);
+    philox_block_plain(seed, subseq, (uint64_t)j, o);
+    raw[8 * j + 0] = h0; raw[8 * j + 1] = h1; raw[8 * j + 2] = h2; raw[8 * j + 3] = h3;
+    for (int c = 0; c < 4; c++) raw[8 * j + 4 + c] = o[c];
+}
+
+}  // namespace hwk

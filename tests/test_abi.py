@@ -1,0 +1,82 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds for gfx950, loads, exports every
+symbol include/hw_mc.h declares, and its host-only entry points behave (no GPU compute here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+
+def _declared_symbols():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "hw_mc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hw_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol(hwmc_mod):
+    assert os.path.exists(hwmc_mod.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 24
+    assert sorted(hwmc_mod.SIGNATURES) == declared        # python binding covers the whole header
+    lib = C.CDLL(hwmc_mod.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    out = subprocess.run(["nm", "-D", "--defined-only", hwmc_mod.LIB_PATH], capture_output=True, text=True).stdout
+    for name in declared:
+        assert re.search(r"\bT %s\b" % name, out), name
+
+
+def test_library_contains_gfx950_code_object(hwmc_mod):
+    data = open(hwmc_mod.LIB_PATH, "rb").read()
+    assert b"gfx950" in data
+    assert b"zbc_superposed_kernel" in data
+
+
+def test_host_only_entry_points(hwmc_mod):
+    p = hwmc_mod.default_params("head")
+    assert (p.a, p.sigma, p.r0, p.T_final, p.n_steps, p.n_mat) == (1.0, 0.1, 0.012, 10.0, 1000, 101)
+    assert p.th_a2 == 0.019 and hwmc_mod.default_params("readme").th_a2 == 0.014
+    with pytest.raises(hwmc_mod.HwError):
+        hwmc_mod.default_params("nope")
+    P, f = hwmc_mod.analytic_curve(p)
+    assert P[0] == 1.0 and float(P[50]) == pytest.approx(0.947126, abs=1e-6)
+    assert float(f[0]) == pytest.approx(0.012, abs=1e-7)
+    r = hwmc_mod.cv_price([2.0, 4.0, 3.0, 9.0, 5.0], 2, 1.9)
+    assert r["mean_X"] == 1.0 and r["mean_Y"] == 2.0 and r["beta"] == pytest.approx(1.0)
+    assert r["price"] == pytest.approx(1.0 - 0.1)
+
+
+def test_host_post_processing_matches_oracle(hwmc_mod, oracle_mod):
+    p = hwmc_mod.default_params("head")
+    P, f = hwmc_mod.analytic_curve(p)
+    o = oracle_mod.Oracle("head")
+    c = o.zcb_curve(512, 5)
+    Po, fo = o.average_and_forward(c, 1024)
+    Pe = np.zeros(101, np.float32)
+    fe = np.zeros(101, np.float32)
+    lib = C.CDLL(hwmc_mod.LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    fp = C.POINTER(C.c_float)
+    rc = lib.hw_average_and_forward(C.byref(p), c.ctypes.data_as(dp), C.c_int64(1024),
+                                    Pe.ctypes.data_as(fp), fe.ctypes.data_as(fp))
+    assert rc == 0
+    np.testing.assert_array_equal(Pe, Po)
+    np.testing.assert_allclose(fe, fo, rtol=0, atol=1e-7)
+    s = o.zbc_moments(P, f, 4096, 9)
+    ro = o.cv_price(s, 8192, float(P[-1]))
+    re_ = hwmc_mod.cv_price(s, 8192, float(P[-1]))
+    for k in ("price", "beta", "rho", "mean_X", "mean_Y"):
+        assert re_[k] == pytest.approx(ro[k], rel=2e-5)       # float32 vs double post-processing
+
+
+def test_no_gpu_gives_error_not_fallback(hwmc_mod):
+    """Without a GPU hw_create must fail loudly (HW_E_HIP); with one, it must succeed."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(hwmc_mod.HwError) as ei:
+        hwmc_mod.HullWhiteEngine(hwmc_mod.default_params("head"))
+    assert ei.value.code == -2

@@ -1,0 +1,319 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same Philox stream, against the committed golden vectors, and --
+at BASELINE.json's full sizes -- through size-independent properties.
+
+Tolerances (north_star: prices, beta*, Vega within 1e-5 relative; integer path counts exact):
+  REL_F32 = 1e-5  moments / price / beta* of the float32 engine vs the float32 oracle.  The GPU
+                  uses the hardware v_log/v_sqrt/v_sin/v_cos/v_exp approximations and the
+                  superposed stepper (different rounding order), the oracle uses libm and the
+                  reference's per-step arithmetic; observed differences are ~1e-7..1e-6.
+  REL_F64 = 2e-6  float64 engine vs float64 oracle: both consume the SAME float32 Box-Muller
+                  normals, whose GPU/libm transcendental differences (~1e-7 per draw) set the floor.
+  Philox words: bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_F32 = 1e-5
+REL_F64 = 2e-6
+
+
+@pytest.fixture(scope="module")
+def setup(hwmc_mod, oracle_mod):
+    engines = {}
+
+    def get(profile="head", precision="f32", n_steps=1000, table_mode="f64"):
+        key = (profile, precision, n_steps, table_mode)
+        if key not in engines:
+            p = hwmc_mod.default_params(profile, n_steps=n_steps, precision=precision, table_mode=table_mode)
+            e = hwmc_mod.HullWhiteEngine(p, device=0)
+            P, f = hwmc_mod.analytic_curve(p)
+            e.load_market_data(P, f)
+            o = oracle_mod.Oracle(profile, n_steps=n_steps, precision=precision)
+            engines[key] = (e, o, P, f)
+        return engines[key]
+
+    yield get
+    for e, _, _, _ in engines.values():
+        e.close()
+
+
+def _price(hwmc_mod, sums, n_pairs, P):
+    return hwmc_mod.cv_price(sums, 2 * n_pairs, float(P[-1]))
+
+
+# ---- RNG --------------------------------------------------------------------------------------
+def test_device_philox_bit_exact_vs_rocrand_and_oracle(setup, rocrand_vectors):
+    e, o, _, _ = setup()
+    for v in rocrand_vectors["vectors"]:
+        got = e.debug_raw(v["seed"], v["subsequence"], 3).reshape(-1).tolist()
+        assert got == v["words"], (v["seed"], v["subsequence"])
+    # deep into a path (block 124 = steps 496..499) and 64-bit ids
+    for seed, sub in ((1234, 0), (20240613, 123456789012), (2 ** 63 + 5, 2 ** 40 + 3)):
+        raw = e.debug_raw(seed, sub, 125)
+        for b in (0, 1, 63, 124):
+            assert raw[b].tolist() == o.uint4(seed, sub, b)
+
+
+def test_device_normals_vs_oracle_and_rocrand(setup, rocrand_vectors, golden):
+    e, o, _, _ = setup()
+    worst = 0.0
+    for v in rocrand_vectors["vectors"]:
+        got = e.debug_normals(v["seed"], v["subsequence"], 3).reshape(-1)
+        worst = max(worst, float(np.max(np.abs(got - np.array(v["normals"], np.float32)))))
+    for g in golden["normals"]:
+        got = e.debug_normals(g["seed"], g["subsequence"], g["block"] + 1)[g["block"]]
+        worst = max(worst, float(np.max(np.abs(got - np.array(g["g"], np.float32)))))
+    # hardware sin/cos/log/sqrt vs libm: absolute error of a N(0,1) draw
+    assert worst < 2e-5, worst
+    # moments of 2^16 device normals
+    z = e.debug_normals(99, 7, 1 << 14).reshape(-1).astype(np.float64)
+    assert abs(z.mean()) < 4 / math.sqrt(z.size)
+    assert abs(z.var() - 1.0) < 4 * math.sqrt(2.0 / z.size)
+
+
+# ---- ZBC: the north-star kernel -----------------------------------------------------------------
+@pytest.mark.parametrize("profile", ["head", "readme"])
+@pytest.mark.parametrize("stepper", ["superposed", "reference"])
+def test_zbc_moments_vs_oracle_f32(setup, hwmc_mod, profile, stepper):
+    e, o, P, f = setup(profile)
+    st = hwmc_mod.HW_STEPPER_SUPERPOSED if stepper == "superposed" else hwmc_mod.HW_STEPPER_REFERENCE
+    for n, seed in ((1 << 10, 1234), (1 << 14, 20240613), (1 << 16, 42)):
+        got = e.simulate_ZBC_control_variate(n, seed, stepper=st)
+        want = o.zbc_moments(P, f, n, seed)
+        np.testing.assert_allclose(got, want, rtol=REL_F32)
+        pg, pw = _price(hwmc_mod, got, n, P), _price(hwmc_mod, want, n, P)
+        assert pg["price"] == pytest.approx(pw["price"], rel=REL_F32)
+        assert pg["beta"] == pytest.approx(pw["beta"], rel=REL_F32)
+
+
+def test_zbc_moments_vs_golden_fixture(setup, hwmc_mod, golden):
+    for case in golden["cases"]:
+        e, _, P, f = setup(case["profile"], case["precision"])
+        got = e.simulate_ZBC_control_variate(case["n"], case["seed"], path_offset=case["path_offset"])
+        tol = REL_F32 if case["precision"] == "f32" else REL_F64
+        np.testing.assert_allclose(got, case["zbc_sums"], rtol=tol)
+
+
+def test_zbc_f64_engine_vs_oracle_f64(setup, hwmc_mod):
+    e, o, P, f = setup("head", "f64")
+    n = 1 << 14
+    got = e.simulate_ZBC_control_variate(n, 7)
+    want = o.zbc_moments(P, f, n, 7)
+    np.testing.assert_allclose(got, want, rtol=REL_F64)
+
+
+def test_zbc_reference_tables_mode(setup, hwmc_mod):
+    """table_mode=ref_f32 (the reference's float32 host tables) against the float32 oracle."""
+    e, o, P, f = setup("head", "f32", 1000, "ref_f32")
+    n = 1 << 14
+    for st in (hwmc_mod.HW_STEPPER_SUPERPOSED, hwmc_mod.HW_STEPPER_REFERENCE):
+        got = e.simulate_ZBC_control_variate(n, 5, stepper=st)
+        np.testing.assert_allclose(got, o.zbc_moments(P, f, n, 5), rtol=REL_F32)
+    d, sd = e.drift_tables()
+    do, sdo = o.tables()
+    np.testing.assert_array_equal(d.astype(np.float32), do)       # same float32 arithmetic
+    np.testing.assert_allclose(sd, sdo, rtol=2e-5)                # coshf difference: clang vs glibc paths agree to ulps
+
+
+def test_zbc_lds_table_variant_and_launch_knobs(setup, hwmc_mod):
+    e, o, P, f = setup("head")
+    n = 5000
+    want = o.zbc_moments(P, f, n, 77)
+    try:
+        for block, cap, lds, ilp in ((256, 0, 1, 1), (64, 1, 0, 1), (1024, 1, 1, 2), (512, 2, 0, 2), (128, 0, 0, 2)):
+            e.set_launch(block, cap, lds, ilp)
+            for st in (hwmc_mod.HW_STEPPER_SUPERPOSED, hwmc_mod.HW_STEPPER_REFERENCE):
+                got = e.simulate_ZBC_control_variate(n, 77, stepper=st)
+                np.testing.assert_allclose(got, want, rtol=REL_F32)
+    finally:
+        e.set_launch(256, 0, 0, 1)
+
+
+def test_zbc_edge_cases_and_sharding(setup, hwmc_mod):
+    e, o, P, f = setup("head")
+    assert np.all(e.simulate_ZBC_control_variate(0, 1) == 0.0)                    # empty
+    one = e.simulate_ZBC_control_variate(1, 1)                                    # single pair
+    np.testing.assert_allclose(one, o.zbc_moments(P, f, 1, 1), rtol=REL_F32)
+    # ragged sizes around the block / wave boundaries, huge 64-bit offsets
+    for n in (63, 64, 65, 255, 257, 1000):
+        got = e.simulate_ZBC_control_variate(n, 3, path_offset=2 ** 40 + 17)
+        np.testing.assert_allclose(got, o.zbc_moments(P, f, n, 3, path_offset=2 ** 40 + 17), rtol=REL_F32)
+    # shards by path_offset add up to the whole (what the multi-GPU path relies on)
+    whole = e.simulate_ZBC_control_variate(10000, 9)
+    parts = sum(e.simulate_ZBC_control_variate(m, 9, path_offset=off)
+                for off, m in ((0, 2500), (2500, 2500), (5000, 1234), (6234, 3766)))
+    np.testing.assert_allclose(whole, parts, rtol=1e-13)
+    # bit-reproducible: the reduction order is fixed
+    again = e.simulate_ZBC_control_variate(10000, 9)
+    assert np.array_equal(whole, again)
+    # a different seed gives different numbers
+    assert not np.array_equal(whole, e.simulate_ZBC_control_variate(10000, 10))
+
+
+def test_zbc_other_option_and_grid(setup, hwmc_mod):
+    """S1/S2/K other than the hard-coded 5/10/e^-0.1, a 4000-step grid (2000 executed steps) and a
+    step count that is not a multiple of 4 (tail of the 4-normals-per-Philox-block loop)."""
+    e, o, P, f = setup("head")
+    got = e.simulate_ZBC_control_variate(4096, 11, S1=2.5, S2=7.3, K=0.8)
+    np.testing.assert_allclose(got, o.zbc_moments(P, f, 4096, 11, S1=2.5, S2=7.3, K=0.8), rtol=REL_F32)
+    got = e.simulate_ZBC_control_variate(4096, 11, S1=4.97, S2=9.0, K=0.9)        # 497 steps
+    assert o.steps_to(4.97) == 497
+    np.testing.assert_allclose(got, o.zbc_moments(P, f, 4096, 11, S1=4.97, S2=9.0, K=0.9), rtol=REL_F32)
+    e4, o4, P4, f4 = setup("head", "f32", 4000)
+    for st in (hwmc_mod.HW_STEPPER_SUPERPOSED, hwmc_mod.HW_STEPPER_REFERENCE):
+        got = e4.simulate_ZBC_control_variate(2048, 13, stepper=st)
+        np.testing.assert_allclose(got, o4.zbc_moments(P4, f4, 2048, 13), rtol=REL_F32)
+
+
+def test_error_behaviour(hwmc_mod):
+    p = hwmc_mod.default_params("head")
+    e = hwmc_mod.HullWhiteEngine(p, device=0)
+    try:
+        with pytest.raises(hwmc_mod.HwError) as ei:                # "Did you run Q1 first?"
+            e.simulate_ZBC_control_variate(16, 1)
+        assert ei.value.code == -3
+        P, f = hwmc_mod.analytic_curve(p)
+        with pytest.raises(hwmc_mod.HwError):                      # wrong curve length
+            e.load_market_data(P[:50], f[:50])
+        e.load_market_data(P, f)
+        for bad in (dict(S1=0.0), dict(S1=6.0, S2=5.0), dict(S2=11.0)):
+            with pytest.raises(hwmc_mod.HwError):
+                e.simulate_ZBC_control_variate(16, 1, **bad)
+        with pytest.raises(hwmc_mod.HwError):
+            e.simulate_ZBC_control_variate(-1, 1)
+        with pytest.raises(hwmc_mod.HwError):
+            e.set_launch(100, 0, 0, 1)
+    finally:
+        e.close()
+    bad = hwmc_mod.default_params("head", n_steps=1001)            # common.cuh:25-27 static check
+    with pytest.raises(hwmc_mod.HwError):
+        hwmc_mod.HullWhiteEngine(bad, device=0)
+
+
+# ---- curve kernel -------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_zcb_curve_vs_oracle(setup, hwmc_mod, golden, precision):
+    e, o, P, f = setup("head", precision)
+    tol = REL_F32 if precision == "f32" else REL_F64
+    for n, seed in ((1 << 10, 1234), (3000, 5)):
+        got = e.simulate_zcb(n, seed)
+        want = o.zcb_curve(n, seed)
+        assert got[0] == 2.0 * n                                   # path count: exact
+        np.testing.assert_allclose(got, want, rtol=tol)
+    for case in golden["cases"]:
+        if "zcb_P_sum" in case and case["profile"] == "head" and case["precision"] == precision:
+            got = e.simulate_zcb(case["n"], case["seed"])
+            np.testing.assert_allclose(got, case["zcb_P_sum"], rtol=tol)
+    # host post-processing of the curve equals the oracle's (compute_average_and_forward)
+    c = e.simulate_zcb(1024, 1234)
+    Pg, fg = e.compute_average_and_forward(c, 2048)
+    Po, fo = o.average_and_forward(c, 2048)
+    assert Pg[0] == 1.0
+    np.testing.assert_array_equal(Pg, Po)
+    np.testing.assert_allclose(fg, fo, rtol=0, atol=1e-7)
+    # sharding + reproducibility
+    whole = e.simulate_zcb(5000, 21)
+    parts = e.simulate_zcb(2000, 21) + e.simulate_zcb(3000, 21, path_offset=2000)
+    np.testing.assert_allclose(whole[1:], parts[1:], rtol=1e-13)
+    assert np.array_equal(whole, e.simulate_zcb(5000, 21))
+
+
+def test_zcb_curve_other_sigma_and_grid(setup):
+    e, o, P, f = setup("head")
+    got = e.simulate_zcb(2048, 3, sigma=0.101)                     # recompute_market_data, 3_sens:449-482
+    np.testing.assert_allclose(got, o.zcb_curve(2048, 3, sigma=0.101), rtol=REL_F32)
+    e4, o4, _, _ = setup("head", "f32", 4000)
+    np.testing.assert_allclose(e4.simulate_zcb(512, 3), o4.zcb_curve(512, 3), rtol=REL_F32)
+
+
+# ---- Vega ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_vega_pathwise_vs_oracle(setup, golden, precision):
+    e, o, P, f = setup("head", precision)
+    # the indicator 1{P>K} can flip on a path within rounding of the strike: a flip moves the sum
+    # by ~0.3, i.e. ~1e-4 relative at 2^14 paths; none occurs for these seeds, and REL_F32 holds.
+    tol = REL_F32 if precision == "f32" else REL_F64
+    for n, seed in ((1 << 10, 1234), (1 << 14, 20240613), (777, 3)):
+        got = e.simulate_sensitivity(n, seed)
+        assert got == pytest.approx(o.vega_pathwise(P, f, n, seed), rel=tol)
+    for case in golden["cases"]:
+        if case["profile"] == "head" and case["precision"] == precision:
+            got = e.simulate_sensitivity(case["n"], case["seed"], path_offset=case["path_offset"])
+            assert got == pytest.approx(case["vega_sum"], rel=tol)
+    a = e.simulate_sensitivity(4096, 5, antithetic=True)
+    b = e.simulate_sensitivity(4096, 5)
+    assert a != b and abs(a / 8192 - b / 4096) < 0.02
+
+
+def test_finite_difference_vega(setup, hwmc_mod, golden):
+    e, o, P, f = setup("head")
+    n, seed, eps = 1 << 14, 1234, 1e-3
+    s0 = o.sigma
+    want = []
+    for sg in (s0 - eps, s0 + eps):
+        sm = o.zbc_moments(P, f, n, seed, sigma=sg, drift=o.shifted_drift(sg, s0))
+        want.append(sm)
+    sc = e.simulate_ZBC_scenarios(n, seed, [s0 - eps, s0 + eps], [hwmc_mod.HW_DRIFT_SHIFTED] * 2)
+    np.testing.assert_allclose(sc[0], want[0], rtol=REL_F32)
+    np.testing.assert_allclose(sc[1], want[1], rtol=REL_F32)
+    fused = e.run_finite_difference(n, seed, eps, fused=True)
+    split = e.run_finite_difference(n, seed, eps, fused=False)
+    assert fused["vega_fd"] == pytest.approx(split["vega_fd"], rel=1e-9)        # same draws, same arithmetic
+    pw = [hwmc_mod.cv_price(w, 2 * n, float(P[-1]))["price"] for w in want]
+    # a price difference of 5e-4 carries the 1e-5 relative price tolerance amplified ~50x
+    assert fused["vega_fd"] == pytest.approx((pw[1] - pw[0]) / (2 * eps), rel=1e-3)
+    for case in golden["cases"]:
+        if "zbc_sums_fd" in case and case["profile"] == "head" and case["precision"] == "f32":
+            sc = e.simulate_ZBC_scenarios(case["n"], case["seed"], [s0 - eps, s0, s0 + eps],
+                                          [hwmc_mod.HW_DRIFT_SHIFTED, hwmc_mod.HW_DRIFT_BASE, hwmc_mod.HW_DRIFT_SHIFTED])
+            np.testing.assert_allclose(sc[0], case["zbc_sums_fd"][0], rtol=REL_F32)
+            np.testing.assert_allclose(sc[2], case["zbc_sums_fd"][1], rtol=REL_F32)
+            np.testing.assert_allclose(sc[1], case["zbc_sums"], rtol=REL_F32)
+
+
+def test_sample_paths_vs_oracle(setup, golden):
+    e, o, _, _ = setup("head")
+    got = e.simulate_paths_show(32, 4242)
+    assert got.shape == (32, 1001) and got.dtype == np.float32      # analyze.py:15-27 layout
+    want = o.sample_paths(32, 4242)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+    g = golden["sample_paths_head"]
+    np.testing.assert_allclose(got[:3][:, g["r_at"]], np.array(g["r"]), rtol=0, atol=2e-6)
+    assert np.all(got[:, 0] == np.float32(0.012))
+
+
+# ---- BASELINE.json sizes: size-independent properties ---------------------------------------------
+def test_full_size_properties_2pow20(setup, hwmc_mod):
+    """Q2b at 2^20 pairs x 1000-step grid (configs[1]) and Q3 at 2^20 paths (configs[2])."""
+    e, o, P, f = setup("readme")
+    n = 1 << 20
+    whole, ms = e.simulate_ZBC_control_variate(n, 1234, return_ms=True)
+    assert np.array_equal(whole, e.simulate_ZBC_control_variate(n, 1234))           # reproducible
+    halves = sum(e.simulate_ZBC_control_variate(n // 2, 1234, path_offset=k * (n // 2)) for k in range(2))
+    np.testing.assert_allclose(whole, halves, rtol=1e-13)                           # shards add up
+    eighths = sum(e.simulate_ZBC_control_variate(n // 8, 1234, path_offset=k * (n // 8)) for k in range(8))
+    np.testing.assert_allclose(whole, eighths, rtol=1e-13)
+    ref = e.simulate_ZBC_control_variate(n, 1234, stepper=hwmc_mod.HW_STEPPER_REFERENCE)
+    np.testing.assert_allclose(whole, ref, rtol=REL_F32)                            # two steppers agree
+    # an oracle sample of the same stream: pairs [0, 2^15) are a shard of the full run
+    m = 1 << 15
+    np.testing.assert_allclose(e.simulate_ZBC_control_variate(m, 1234), o.zbc_moments(P, f, m, 1234), rtol=REL_F32)
+    r = hwmc_mod.cv_price(whole, 2 * n, float(P[-1]))
+    assert abs(r["price"] - 0.03544557) < 4 * r["ci95_halfwidth"] / 1.96            # exact Jamshidian
+    assert r["beta"] == pytest.approx(0.166309, abs=1e-3)
+    assert r["rho"] == pytest.approx(0.6738, abs=2e-3)
+    vega = e.simulate_sensitivity(n, 99) / n
+    assert vega == pytest.approx(0.230244, abs=1.5e-3)                              # analytic Vega
+    fd = e.run_finite_difference(n, 99)
+    assert fd["vega_fd"] == pytest.approx(0.230244, abs=2e-3)
+    assert abs(fd["vega_fd"] - vega) / vega < 0.02                                  # README.md:49-50: 0.18 %
+    c = e.simulate_zcb(n, 5)
+    assert c[0] == 2.0 * n
+    Pmc, fmc = e.compute_average_and_forward(c, 2 * n)
+    assert float(np.max(np.abs(Pmc - P))) < 4e-4                                    # ~4 SE at 2^21 paths
+    assert ms > 0
