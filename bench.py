@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the Hull-White Monte Carlo hot path on MI355X.
+
+Metric (BASELINE.json): M paths/sec of the ZBC option kernel (2^20 antithetic pairs per GPU,
+1000-step grid over T=10 -> 500 executed steps to S1=5, optimal-beta control variate),
+throughput defined exactly as the reference does: (2*N_PATHS / ms) / 1000
+(src/2_option_pricing.cu:198).  One "step" = one pricing call = one launch of the path kernel
+over the whole batch + the reduction of its five moment sums; the K timed steps use K different
+seeds, i.e. they ARE the reference's 20-run statistical validation (2_option:210-468), from
+which the 95 % CI width of the metric is computed.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU; rank g prices global pairs [g*n, (g+1)*n) of an N*n-pair run (weak
+scaling), and each step's five moment sums are all-reduced over RCCL (asynchronously, so the
+all-reduce of step i overlaps the kernel of step i+1).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# VALU issue model of the path kernel's inner loop, per Philox block = 4 time steps of one pair
+# (instruction counts from the gfx950 disassembly, issue cycles per wave64 instruction per SIMD
+#  measured by tools/valu_rates.hip on MI355X: full rate 2, half rate 4, quarter rate 8).
+VALU_MODEL = {
+    "superposed": {"full": 53, "half": 21, "quarter": 8},   # 34 xor,4 fmamk,6 mul,4 fmac,4 add,1 mov | 17 mad_u64,4 cvt | 2 log,2 sqrt,2 sin,2 cos
+    "reference": {"full": 81, "half": 21, "quarter": 8},    # + per-step: sG mul, 2 add, 2 fma, 2 add, 2 mul/fma pairs on two legs
+}
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+V100_PUBLISHED_MPATHS = 1064.0  # BASELINE.md section 1 (reference README.md:44,162; one V100)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--paths-log2", type=int, default=20, help="antithetic pairs per GPU (log2)")
+    ap.add_argument("--grid-steps", type=int, default=1000)
+    ap.add_argument("--stepper", default="superposed", choices=["superposed", "reference"])
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--profile", default="head", choices=["head", "readme"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--spinup-ms", type=float, default=400.0,
+                    help="untimed launches before the W warm-up steps so the timed region runs at the "
+                         "clock the chip holds under sustained load (DVFS ramps over the first ~100 ms)")
+    return ap.parse_args()
+
+
+def cpu_baseline(P, f, profile, grid_steps, seconds):
+    """The oracle's OpenMP loop (same stepper, same Philox stream) on this host's cores, on a
+    bounded sample of the same workload; throughput is per path so it compares directly."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import hw_oracle
+    o = hw_oracle.Oracle(profile, n_steps=grid_steps)
+    cores = o.max_threads()
+    t0 = time.perf_counter()
+    o.zbc_moments(P, f, 1 << 13, 1)                      # calibration
+    rate = (1 << 13) / max(time.perf_counter() - t0, 1e-6)
+    n = int(min(max(rate * seconds, 1 << 13), 1 << 23))
+    t0 = time.perf_counter()
+    o.zbc_moments(P, f, n, 2)
+    dt = time.perf_counter() - t0
+    n1 = max(n // (4 * cores), 1 << 10)
+    t0 = time.perf_counter()
+    o.zbc_moments(P, f, n1, 3, n_threads=1)
+    dt1 = time.perf_counter() - t0
+    return {"value": 2 * n / dt / 1e6, "unit": "M paths/s", "cores": cores, "kind": "port",
+            "sample": "%d antithetic pairs x %d executed steps, OpenMP %d threads, %.1f s (oracle/hw_oracle.c)"
+                      % (n, o.steps_to(5.0), cores, dt),
+            "single_thread_value": 2 * n1 / dt1 / 1e6,
+            "single_thread_sample": "%d pairs, %.1f s" % (n1, dt1)}
+
+
+def main():
+    a = parse()
+    import torch                                       # first: libhw_hip.so then shares torch's HIP runtime
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import numpy as np
+    import hwmc
+    n_pairs = 1 << a.paths_log2
+    p = hwmc.default_params(a.profile, n_steps=a.grid_steps, precision=a.precision)
+    e = hwmc.HullWhiteEngine(p, device=local_rank)
+    P, f = hwmc.analytic_curve(p)                      # synthetic market input (exact curve)
+    e.load_market_data(P, f)
+    stepper = hwmc.HW_STEPPER_SUPERPOSED if a.stepper == "superposed" else hwmc.HW_STEPPER_REFERENCE
+    K, W = a.steps, a.warmup
+    out = torch.zeros((K + W, 5), dtype=torch.float64, device=dev)
+    # An explicit side stream, made torch's CURRENT stream for everything below: the kernels are
+    # enqueued on it through the C ABI, torch's events time it and RCCL orders its all-reduce
+    # after it.  (A NULL handle would mean "the context's own stream" to the C ABI.)
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(side)
+    stream = side.cuda_stream
+    assert stream != 0
+    # weak scaling: an (N * n_pairs)-pair run, rank g owns the contiguous shard hwmc.parallel.shard gives it
+    offset, shard_n = hwmc.parallel.shard(n_pairs * world, rank, world)
+    assert shard_n == n_pairs
+
+    def step(i, seed):
+        e.enqueue_ZBC(out[i].data_ptr(), n_pairs, seed, path_offset=offset, stepper=stepper, stream=stream)
+        return hwmc.parallel.allreduce_sums(out[i], async_op=True)     # None in a single process
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t_spin = time.perf_counter()
+    while (time.perf_counter() - t_spin) * 1e3 < a.spinup_ms:      # untimed: bring the clocks up
+        for _ in range(8):
+            e.enqueue_ZBC(out[0].data_ptr(), n_pairs, 7, path_offset=offset, stepper=stepper, stream=stream)
+        torch.cuda.synchronize()
+    for i in range(W):
+        w = step(i, 900 + i)
+        if w is not None:
+            w.wait()
+    fence()
+    # One HIP event pair brackets the K timed launches on the stream they are launched on (torch's
+    # current stream IS that stream): average launch duration = region / K.  Per-launch event pairs
+    # would cost ~7 us of queue bubbles per step, so they are taken in a second, untimed pass below.
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    works = []
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(K):
+        works.append(step(W + i, 1234 + 12345 * i))       # seeds as 2_option:229: base + run*12345
+    ev1.record()
+    for w in works:
+        if w is not None:
+            w.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    region_ms = ev0.elapsed_time(ev1)
+    e.profile_enable(K)                                    # untimed pass: isolated per-launch durations
+    for i in range(K):
+        e.enqueue_ZBC(out[W + i].data_ptr(), n_pairs, 1234 + 12345 * i, path_offset=offset, stepper=stepper, stream=stream)
+    torch.cuda.synchronize()
+    kernel_ms = e.profile_read(K)
+    clock_mhz = e.profile_clock_mhz() if a.stepper == "superposed" else None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    sums = out[W:].cpu().numpy()
+    if rank == 0:
+        n_total = 2 * n_pairs * world
+        prices = [hwmc.cv_price(s, n_total, float(P[-1])) for s in sums]
+        st = hwmc.run_statistics([r["price"] for r in prices])
+        ms_per_step = elapsed * 1e3 / K
+        value = (n_total / ms_per_step) / 1000.0
+        steps_exec = int(round(5.0 * a.grid_steps / 10.0))
+        info = e.device_info()
+        kavg = region_ms / K                               # HIP events over the timed region
+        geo_blocks = min((n_pairs + 255) // 256, info["compute_units"] * 8)
+        algo_bytes = geo_blocks * 5 * 8 + 5 * 8            # partial rows written + the 5 sums (stateless Philox: no state traffic)
+        achieved = algo_bytes / (kavg * 1e-3) / 1e9
+        vm = VALU_MODEL[a.stepper]
+        cyc_per_block = 2 * vm["full"] + 4 * vm["half"] + 8 * vm["quarter"]
+        waves = (n_pairs + 63) // 64
+        simd_cycles = waves * (steps_exec / 4.0) * cyc_per_block
+        valu_frac = simd_cycles / (info["compute_units"] * 4 * info["clock_mhz"] * 1e6 * kavg * 1e-3)
+        line = {
+            "metric": "M paths/sec (ZBC option, 1000 steps)", "value": round(value, 2), "unit": "M paths/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": round(value / V100_PUBLISHED_MPATHS, 3),
+            "baseline": {"value": V100_PUBLISHED_MPATHS, "unit": "M paths/s", "hardware": "1x Tesla V100",
+                         "source": "reference README.md:44,162 (single un-warmed launch)"},
+            "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": "Q2b option_pricing: 2^%d antithetic pairs per GPU x %d-step grid (%d executed to S1=5), "
+                                   "optimal-beta control variate, %d x MI355X" % (a.paths_log2, a.grid_steps, steps_exec, world),
+                       "pairs_per_gpu": n_pairs, "effective_paths": n_total, "grid_steps": a.grid_steps,
+                       "steps_executed": steps_exec, "stepper": a.stepper, "theta_profile": a.profile,
+                       "rng": "Philox4x32-10 (rocRAND layout), stateless, subsequence = global pair id",
+                       "parallelism": "paths sharded by global id; one RCCL all-reduce of 5 f64 moments per step" if world > 1 else "single GPU"},
+            "thread_steps_per_sec": n_pairs * world * steps_exec / (ms_per_step * 1e-3),
+            "price_mean": st["mean"], "ci95_width": st["ci95_width"], "ci95_halfwidth_single_run": prices[0]["ci95_halfwidth"],
+            "beta_mean": float(np.mean([r["beta"] for r in prices])),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "zbc_%s_kernel" % a.stepper, "kernel_ms_avg": kavg, "kernel_ms_per_launch_events": {"avg": float(np.mean(kernel_ms)), "min": float(np.min(kernel_ms))},
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "stateless Philox: the path kernel has ~0 algorithmic HBM traffic; the binding roof is VALU issue (see valu)"},
+            "valu": {"bound": "valu-issue", "issue_cycles_per_wave_per_4_steps": cyc_per_block,
+                     "instr_per_4_steps": vm, "clock_mhz_nominal": info["clock_mhz"], "frac_of_nominal_clock_peak": valu_frac,
+                     "clock_mhz_in_kernel": clock_mhz,
+                     "frac_at_measured_clock": (valu_frac * info["clock_mhz"] / clock_mhz) if clock_mhz else None},
+            "kernel_Mpaths_per_sec": (2 * n_pairs / kavg) / 1000.0,
+            "device": info["name"],
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(P, f, a.profile, a.grid_steps, a.cpu_seconds)
+        print(json.dumps(line))
+    e.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

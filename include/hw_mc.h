@@ -171,6 +171,9 @@ int  hw_debug_raw(hw_ctx* ctx, uint64_t seed, uint64_t subseq, int32_t n_blocks,
  * and writes the elapsed milliseconds (returns the count via *n_out) and disables profiling. */
 int  hw_profile_enable(hw_ctx* ctx, int32_t max_launches);
 int  hw_profile_read(hw_ctx* ctx, float* ms, int32_t cap, int32_t* n_out);
+/* Shader clock (MHz) the chip held during the last profiled superposed-ZBC launch, from an
+ * in-kernel s_memtime / s_memrealtime probe in workgroup 0 (read after the launch completed). */
+int  hw_profile_clock(hw_ctx* ctx, double* shader_mhz);
 
 int  hw_get_kernel_info(hw_ctx* ctx, const char* kernel /* "zbc" | "zbc_ref" | "zcb" | "vega" */,
                         hw_kernel_info* out);

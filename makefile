@@ -1,0 +1,59 @@
+# Same targets as the reference's makefile (all q1 q2 q3 run-q1 run-q2 run-q3 run-all analyze clean
+# clean-all); the toolchain is hipcc for gfx950 and the executables link the C-ABI engine library.
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX   ?= g++
+PKG   = monte-carlo-simulation-of-hull-white-model-and-sensitivities-computation_amd
+LIB   = $(PKG)/libhw_hip.so
+CXXFLAGS = -O2 -std=c++17 -Wall -Wextra -I include
+LDFLAGS  = -L$(PKG) -lhw_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)'
+SRC = src
+BIN = bin
+# the reference pins CUDA_VISIBLE_DEVICES=2 (makefile:27); here the device is a flag: make run-q1 ARGS="--device 2"
+ARGS ?=
+
+all: q1 q2 q3
+
+lib: $(LIB)
+
+$(LIB): $(PKG)/csrc/hw_engine.hip $(PKG)/csrc/hw_kernels.hpp $(PKG)/csrc/hw_model.hpp include/hw_mc.h
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $(PKG)/csrc/hw_engine.hip -o $@
+
+q1: $(SRC)/1_bond_pricing.cpp $(SRC)/hw_app.hpp $(LIB)
+	@mkdir -p $(BIN) data plots
+	$(CXX) $(CXXFLAGS) $< -o $(BIN)/$@ $(LDFLAGS)
+
+q2: $(SRC)/2_option_pricing.cpp $(SRC)/hw_app.hpp $(LIB)
+	@mkdir -p $(BIN) data plots
+	$(CXX) $(CXXFLAGS) $< -o $(BIN)/$@ $(LDFLAGS)
+
+q3: $(SRC)/3_sensitivity_analysis.cpp $(SRC)/hw_app.hpp $(LIB)
+	@mkdir -p $(BIN) data plots
+	$(CXX) $(CXXFLAGS) $< -o $(BIN)/$@ $(LDFLAGS)
+
+run-q1: q1
+	@mkdir -p data plots
+	./$(BIN)/q1 $(ARGS)
+
+run-q2: q2
+	@mkdir -p data plots
+	./$(BIN)/q2 $(ARGS)
+
+run-q3: q3
+	@mkdir -p data plots
+	./$(BIN)/q3 $(ARGS)
+
+run-all: run-q1 run-q2 run-q3
+
+analyze: run-all
+	@echo "run the reference's analyze.py against data/ (same file names and schemas)"
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(BIN) data/*.json data/*.csv data/summary.txt plots/*.png
+
+clean-all:
+	rm -rf $(BIN) data plots
+
+.PHONY: all lib oracle clean clean-all run-q1 run-q2 run-q3 run-all analyze

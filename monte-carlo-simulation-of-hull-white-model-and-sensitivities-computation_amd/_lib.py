@@ -74,6 +74,7 @@ SIGNATURES = {
     "hw_debug_raw": (C.c_int, [_CTX, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_uint32)]),
     "hw_profile_enable": (C.c_int, [_CTX, C.c_int32]),
     "hw_profile_read": (C.c_int, [_CTX, _FP, C.c_int32, C.POINTER(C.c_int32)]),
+    "hw_profile_clock": (C.c_int, [_CTX, _DP]),
     "hw_get_kernel_info": (C.c_int, [_CTX, C.c_char_p, C.POINTER(HwKernelInfo)]),
     "hw_drift_tables": (C.c_int, [_CTX, C.c_double, C.c_int32, _DP, _DP]),
     "hw_average_and_forward": (C.c_int, [C.POINTER(HwParams), _DP, C.c_int64, _FP, _FP]),

@@ -60,6 +60,8 @@ struct hw_ctx {
     double* d_out = nullptr;          // result staging, kOutCap doubles
     double* d_scale = nullptr;        // per-column scale for the curve (n_mat doubles)
     float* d_drift = nullptr;         // float table for the reference stepper / sample paths
+    unsigned* d_ticket = nullptr;     // grid_sum_finish ticket counter (self re-arming)
+    unsigned long long* d_clk = nullptr;  // clock probe of the last superposed ZBC launch (4 words)
     // launch knobs
     int block_size = 256;
     int max_blocks_per_cu = 0;        // in units of block_size-thread workgroups; 0 = default
@@ -188,15 +190,13 @@ int launch_zbc_superposed(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, co
     a.iters = g.iters;
     a.e = (REAL)sc[0].k.e;
     for (int k = 0; k < NSCEN; k++) a.sc[k] = make_scen<REAL>(sc[k], r->K);
+    a.clk = c->prof_cap > 0 ? c->d_clk : nullptr;
     prof_mark(c, st, 0);
     if (ilp == 2)
-        hipLaunchKernelGGL((hwk::zbc_superposed_kernel<REAL, NSCEN, 2>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials);
+        hipLaunchKernelGGL((hwk::zbc_superposed_kernel<REAL, NSCEN, 2>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials, c->d_ticket, d_out);
     else
-        hipLaunchKernelGGL((hwk::zbc_superposed_kernel<REAL, NSCEN, 1>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials);
+        hipLaunchKernelGGL((hwk::zbc_superposed_kernel<REAL, NSCEN, 1>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials, c->d_ticket, d_out);
     prof_mark(c, st, 1);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(5 * NSCEN), dim3(256), 0, st,
-                       (const double*)c->d_partials, g.grid, 5 * NSCEN, (const double*)nullptr, -1.0, d_out);
     HIP_TRY(hipGetLastError());
     return HW_OK;
 }
@@ -226,14 +226,12 @@ int launch_zbc_reference(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, con
     prof_mark(c, st, 0);
     if (c->table_in_lds)
         hipLaunchKernelGGL(hwk::zbc_reference_kernel<1>, dim3(g.grid), dim3(g.block),
-                           (size_t)n_steps_S1 * sizeof(float), st, a, (const float*)c->d_drift, c->d_partials);
+                           (size_t)n_steps_S1 * sizeof(float), st, a, (const float*)c->d_drift, c->d_partials,
+                           c->d_ticket, d_out);
     else
         hipLaunchKernelGGL(hwk::zbc_reference_kernel<0>, dim3(g.grid), dim3(g.block), 0, st, a,
-                           (const float*)c->d_drift, c->d_partials);
+                           (const float*)c->d_drift, c->d_partials, c->d_ticket, d_out);
     prof_mark(c, st, 1);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(5), dim3(256), 0, st, (const double*)c->d_partials,
-                       g.grid, 5, (const double*)nullptr, -1.0, d_out);
     HIP_TRY(hipGetLastError());
     return HW_OK;
 }
@@ -341,13 +339,10 @@ int launch_vega(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset,
     a.zs = (REAL)(s.k.dt * s.k.sig_st / p.sigma);
     prof_mark(c, st, 0);
     if (ilp == 2)
-        hipLaunchKernelGGL((hwk::vega_pathwise_kernel<REAL, 2>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials);
+        hipLaunchKernelGGL((hwk::vega_pathwise_kernel<REAL, 2>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials, c->d_ticket, d_out);
     else
-        hipLaunchKernelGGL((hwk::vega_pathwise_kernel<REAL, 1>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials);
+        hipLaunchKernelGGL((hwk::vega_pathwise_kernel<REAL, 1>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials, c->d_ticket, d_out);
     prof_mark(c, st, 1);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(1), dim3(256), 0, st, (const double*)c->d_partials,
-                       g.grid, 1, (const double*)nullptr, -1.0, d_out);
     HIP_TRY(hipGetLastError());
     return HW_OK;
 }
@@ -437,6 +432,10 @@ int hw_create(const hw_params* p, int device, hw_ctx** out)
     if (e == hipSuccess) e = hipMalloc(&c->d_out, kOutCap * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&c->d_scale, (size_t)p->n_mat * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&c->d_drift, (size_t)p->n_steps * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&c->d_clk, 64);
+    if (e == hipSuccess) e = hipMemset(c->d_clk, 0, 64);
+    if (e == hipSuccess) e = hipMalloc(&c->d_ticket, 64);
+    if (e == hipSuccess) e = hipMemset(c->d_ticket, 0, 64);
     if (e != hipSuccess) {
         hw_destroy(c);
         return fail(HW_E_HIP, "hw_create: %s", hipGetErrorString(e));
@@ -457,6 +456,8 @@ void hw_destroy(hw_ctx* c)
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_scale) (void)hipFree(c->d_scale);
     if (c->d_drift) (void)hipFree(c->d_drift);
+    if (c->d_ticket) (void)hipFree(c->d_ticket);
+    if (c->d_clk) (void)hipFree(c->d_clk);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t ev : c->prof_ev) (void)hipEventDestroy(ev);
@@ -709,6 +710,18 @@ int hw_profile_read(hw_ctx* c, float* ms, int32_t cap, int32_t* n_out)
     *n_out = n;
     c->prof_cap = 0;
     c->prof_used = 0;
+    return HW_OK;
+}
+
+int hw_profile_clock(hw_ctx* c, double* shader_mhz)
+{
+    if (!c || !shader_mhz) return fail(HW_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(h, c->d_clk, sizeof h, hipMemcpyDeviceToHost));
+    if (h[3] <= h[1]) return fail(HW_E_INVALID, "no clock probe recorded (profile a superposed ZBC launch first)");
+    // s_memtime ticks at the shader clock, s_memrealtime at a constant 100 MHz
+    *shader_mhz = (double)(h[2] - h[0]) / (double)(h[3] - h[1]) * 100.0;
     return HW_OK;
 }
 

@@ -167,11 +167,39 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-// Workgroup sum of N doubles per thread -> out[0..N) (one row of the partials buffer).
-// Fixed summation order (lane tree, then waves in index order): bit-reproducible.
-template <int N>
-__device__ __forceinline__ void block_sum_store(double (&v)[N], double* smem /*[kMaxWaves*N]*/, double* out)
+// float sum over the 64 lanes with DPP row operations (no LDS crossbar traffic): the total lands
+// in lane 63.  quad_perm xor-1, xor-2, row_half_mirror, row_mirror give every lane its row-of-16
+// sum; row_bcast:15 / row_bcast:31 carry the row sums across the four rows.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v)
 {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    v += dpp_mov<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xf>(v);   // row_half_mirror
+    v += dpp_mov<0x140, 0xf>(v);   // row_mirror
+    v += dpp_mov<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
+    v += dpp_mov<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// Single-launch finish of a sum over the whole grid: every workgroup stores its row of N partial
+// sums, then takes a ticket; the workgroup that draws the last ticket sums all rows in a FIXED
+// order (rows strided over threads, lane tree, waves in index order) and writes out[0..N), so the
+// result is bit-reproducible whichever workgroup happens to finish last.  Inter-workgroup
+// visibility follows the agent-scope release/acquire recipe: stores -> s_waitcnt vmcnt(0) ->
+// release fence -> s_waitcnt vmcnt(0) -> relaxed agent atomic; the last workgroup: acquire fence
+// by one lane -> s_waitcnt vmcnt(0) -> barrier -> plain loads.  The last workgroup re-arms the
+// ticket counter for the next launch on the stream.
+template <int N>
+__device__ __forceinline__ void grid_sum_finish(double (&v)[N], double* smem /*[kMaxWaves*N]*/,
+                                                double* __restrict__ partials, unsigned* __restrict__ ticket,
+                                                double* __restrict__ out)
+{
+    __shared__ unsigned s_ticket;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int nwaves = (blockDim.x + kWave - 1) >> 6;
 #pragma unroll
@@ -180,11 +208,45 @@ __device__ __forceinline__ void block_sum_store(double (&v)[N], double* smem /*[
         if (lane == 0) smem[wave * N + k] = s;
     }
     __syncthreads();
+    if (wave == 0) {
+        if (lane < N) {
+            double t = 0.0;
+            for (int w = 0; w < nwaves; w++) t += smem[w * N + lane];
+            partials[(size_t)blockIdx.x * N + lane] = t;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave issued all the row's stores
+        if (lane == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;                         // workgroup-uniform
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    double acc[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) acc[k] = 0.0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < N; k++) acc[k] += partials[(size_t)b * N + k];
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const double s = wave_sum(acc[k]);
+        if (lane == 0) smem[wave * N + k] = s;
+    }
+    __syncthreads();
     if (threadIdx.x < N) {
         double t = 0.0;
         for (int w = 0; w < nwaves; w++) t += smem[w * N + threadIdx.x];
         out[threadIdx.x] = t;
     }
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Second (tiny) launch: out[k] = scale[k] * sum_b partials[b*ncol + k], fixed order.
@@ -270,13 +332,21 @@ struct ZbcArgs {
     int32_t n_steps, iters;
     REAL e;
     ZbcScen<REAL> sc[NSCEN];
+    unsigned long long* clk;   // optional: workgroup 0 stores {s_memtime, s_memrealtime} at entry and exit
 };
 
 template <typename REAL, int NSCEN, int ILP>
 __global__ void __launch_bounds__(1024)
-zbc_superposed_kernel(const ZbcArgs<REAL, NSCEN> a, double* __restrict__ partials)
+zbc_superposed_kernel(const ZbcArgs<REAL, NSCEN> a, double* __restrict__ partials,
+                      unsigned* __restrict__ ticket, double* __restrict__ out)
 {
     __shared__ double smem[kMaxWaves * 5 * NSCEN];
+    // clock probe (diagnostic only; the stamps go to a buffer nothing else reads)
+    const bool stamp = a.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    if (stamp) {
+        a.clk[0] = __builtin_amdgcn_s_memtime();
+        a.clk[1] = __builtin_amdgcn_s_memrealtime();
+    }
     const PhiloxKey key = philox_key(a.seed);
     const int64_t T = (int64_t)gridDim.x * blockDim.x;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -320,7 +390,11 @@ zbc_superposed_kernel(const ZbcArgs<REAL, NSCEN> a, double* __restrict__ partial
             }
         }
     }
-    block_sum_store<5 * NSCEN>(acc, smem, partials + (size_t)blockIdx.x * 5 * NSCEN);
+    if (stamp) {
+        a.clk[2] = __builtin_amdgcn_s_memtime();
+        a.clk[3] = __builtin_amdgcn_s_memrealtime();
+    }
+    grid_sum_finish<5 * NSCEN>(acc, smem, partials, ticket, out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -337,7 +411,8 @@ struct ZbcRefArgs {
 
 template <int TABLE_LDS>
 __global__ void __launch_bounds__(1024)
-zbc_reference_kernel(const ZbcRefArgs a, const float* __restrict__ drift, double* __restrict__ partials)
+zbc_reference_kernel(const ZbcRefArgs a, const float* __restrict__ drift, double* __restrict__ partials,
+                     unsigned* __restrict__ ticket, double* __restrict__ out)
 {
     __shared__ double smem[kMaxWaves * 5];
     extern __shared__ float s_drift[];
@@ -389,7 +464,7 @@ zbc_reference_kernel(const ZbcRefArgs a, const float* __restrict__ drift, double
             acc[4] += (double)(x1 * c1 + x2 * c2);
         }
     }
-    block_sum_store<5>(acc, smem, partials + (size_t)blockIdx.x * 5);
+    grid_sum_finish<5>(acc, smem, partials, ticket, out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -397,6 +472,14 @@ zbc_reference_kernel(const ZbcRefArgs a, const float* __restrict__ drift, double
 // maturity m.  The lane-invariant factor D0_m is applied in double by finalize_columns_kernel.
 // Per-wave running sums live in LDS as doubles: row [wave][n_mat], touched by lane 0 only.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float  curve_wave_sum(float q)  { return wave_sum_to_lane63(q); }
+__device__ __forceinline__ double curve_wave_sum(double q)
+{   // total broadcast to every lane (xor butterfly), so lane 63 holds it too
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) q += __shfl_xor(q, off, kWave);
+    return q;
+}
+
 template <typename REAL>
 struct ZcbArgs {
     int64_t n_pairs;
@@ -443,8 +526,8 @@ zcb_curve_kernel(const ZcbArgs<REAL> a, double* __restrict__ partials)
                             const REAL z = a.cz * (S - (REAL)0.5 * y);
                             REAL q = hw_exp2(z) + hw_exp2(-z);             // market_data.cuh:60
                             if (!valid) q = 0;
-                            const REAL qs = wave_sum(q);                   // market_data.cuh:61
-                            if (lane == 0) row[m] += (double)qs;           // market_data.cuh:62-64
+                            const REAL qs = curve_wave_sum(q);             // market_data.cuh:61
+                            if (lane == kWave - 1) row[m] += (double)qs;   // market_data.cuh:62-64
                         }
                     }
                 }
@@ -494,7 +577,8 @@ __device__ __forceinline__ REAL vega_leg(const VegaArgs<REAL>& a, REAL y, REAL h
 
 template <typename REAL, int ILP>
 __global__ void __launch_bounds__(1024)
-vega_pathwise_kernel(const VegaArgs<REAL> a, double* __restrict__ partials)
+vega_pathwise_kernel(const VegaArgs<REAL> a, double* __restrict__ partials,
+                     unsigned* __restrict__ ticket, double* __restrict__ out)
 {
     __shared__ double smem[kMaxWaves];
     const PhiloxKey key = philox_key(a.seed);
@@ -523,7 +607,7 @@ vega_pathwise_kernel(const VegaArgs<REAL> a, double* __restrict__ partials)
             if (valid[q]) acc[0] += (double)v;
         }
     }
-    block_sum_store<1>(acc, smem, partials + blockIdx.x);
+    grid_sum_finish<1>(acc, smem, partials, ticket, out);
 }
 
 // ------------------------------------------------------------------------------------------

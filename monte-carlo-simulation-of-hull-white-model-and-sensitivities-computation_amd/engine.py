@@ -130,6 +130,12 @@ class HullWhiteEngine:
         L.check(self.lib.hw_profile_read(self._ctx, _fp(ms), cap, C.byref(n)))
         return ms[:n.value].copy()
 
+    def profile_clock_mhz(self):
+        """Shader clock held during the last profiled superposed-ZBC launch (in-kernel probe)."""
+        mhz = C.c_double(0.0)
+        L.check(self.lib.hw_profile_clock(self._ctx, C.byref(mhz)))
+        return mhz.value
+
     def set_launch(self, block_size=0, max_blocks_per_cu=0, table_in_lds=0, pairs_in_flight=0):
         L.check(self.lib.hw_set_launch(self._ctx, block_size, max_blocks_per_cu, table_in_lds,
                                        pairs_in_flight))

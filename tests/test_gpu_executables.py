@@ -1,0 +1,83 @@
+"""GPU test of the process surface: bin/q1, bin/q2, bin/q3 run from a scratch directory with the
+reference's ordering dependency (q2/q3 need q1's data/P.bin, data/f.bin) and write the file set and
+schemas the reference's analyze.py consumes (analyze.py:15-27, 64-83, 105-123, 146-153, 257-342)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(exe, cwd, *args, stdin=None, check=True):
+    r = subprocess.run([os.path.join(ROOT, "bin", exe), *args], cwd=cwd, input=stdin, capture_output=True, text=True, timeout=600)
+    if check:
+        assert r.returncode == 0, r.stdout + r.stderr
+    return r
+
+
+@pytest.fixture(scope="module")
+def built():
+    subprocess.check_call(["make", "-C", ROOT, "all"], stdout=subprocess.DEVNULL)
+
+
+def test_q2_without_q1_exits_like_the_reference(built, tmp_path):
+    r = _run("q2", tmp_path, "--no", check=False)
+    assert r.returncode == 1
+    assert "Did you run Q1 first?" in r.stdout                   # common.cuh:155-161
+
+
+def test_three_executables_file_contract(built, tmp_path):
+    d = tmp_path
+    r1 = _run("q1", d, "--paths-log2", "18", "--seed", "1234", "--theta-profile", "readme")
+    for line in ("P(0,0) = 1.0:", "P(0,10) ~ 0.87:", "Throughput:", "Saved data/P.bin (101 floats)"):
+        assert line in r1.stdout
+    assert "ERROR" not in r1.stdout
+    P = np.fromfile(d / "data" / "P.bin", dtype=np.float32)
+    f = np.fromfile(d / "data" / "f.bin", dtype=np.float32)
+    assert P.size == 101 and f.size == 101 and P[0] == 1.0
+    assert abs(P[100] - 0.876777) < 2e-3 and abs(f[0] - 0.012) < 2e-3
+    paths = np.fromfile(d / "data" / "r_paths.bin", dtype=np.float32)
+    assert paths.size == 32 * 1001 and np.all(paths.reshape(32, 1001)[:, 0] == np.float32(0.012))
+    q1 = json.load(open(d / "data" / "q1_results.json"))
+    assert q1["parameters"]["N_PATHS"] == 1 << 18 and q1["parameters"]["N_STEPS"] == 1000
+    assert set(q1["validation"]) == {"P_0_0", "P_0_10", "f_0_0"} and len(q1["P"]) == 101 and len(q1["f"]) == 101
+    assert q1["performance"]["simulation_time_ms"] > 0 and q1["performance"]["throughput_Mpaths_per_sec"] > 0
+    assert open(d / "data" / "P_curve.csv").readline().strip() == "T,P(0 T)"
+    assert open(d / "data" / "f_curve.csv").readline().strip() == "T,f(0 T)"
+    assert "HULL-WHITE MODEL SIMULATION RESULTS" in open(d / "data" / "summary.txt").read()
+
+    # q2: answers "y" on stdin like an interactive user (2_option:495-500)
+    r2 = _run("q2", d, "--paths-log2", "18", "--seed", "99", "--theta-profile", "readme", stdin="y\n")
+    assert "Recovery: SUCCESS" in r2.stdout and "Beta optimal:" in r2.stdout
+    q2a = json.load(open(d / "data" / "q2a_results.json"))
+    assert q2a["error_metrics"]["success"] is True and q2a["error_metrics"]["max_error"] < 0.01
+    q2b = json.load(open(d / "data" / "q2b_results.json"))
+    assert abs(q2b["results"]["ZBC_control_variate"] - 0.0354) < 1.5e-3
+    assert "control_deviation" in q2b["results"] and q2b["performance"]["throughput_Mpaths_per_sec"] > 0
+    assert open(d / "data" / "theta_comparison.csv").readline().strip() == "T,theta_original,theta_recovered"
+    boot = open(d / "data" / "zbc_bootstrap_optimal.csv").read().splitlines()
+    assert boot[0] == "run,price_adjusted,price_raw,beta_optimal,correlation" and len(boot) == 21
+    assert "Variance Reduction:" in open(d / "data" / "zbc_statistics_optimal.txt").read()
+
+    # q3: "n" to the sweep, "y" to the validation (3_sens:725-749)
+    r3 = _run("q3", d, "--paths-log2", "18", "--seed", "5", "--theta-profile", "readme", stdin="n\ny\n")
+    assert "Sign Check:                 PASS" in r3.stdout and "Magnitude Check:            PASS" in r3.stdout
+    q3 = json.load(open(d / "data" / "q3_results.json"))
+    res = q3["results"]
+    assert set(res) == {"sensitivity_mc", "sensitivity_fd", "abs_diff"}
+    assert abs(res["sensitivity_mc"] - 0.2302) < 6e-3 and abs(res["sensitivity_fd"] - 0.2302) < 8e-3
+    vb = open(d / "data" / "vega_bootstrap.csv").read().splitlines()
+    assert vb[0] == "run,vega" and len(vb) == 21
+    assert os.path.exists(d / "data" / "vega_statistics.txt")
+    summary = open(d / "data" / "summary.txt").read()
+    assert "Q1: ZERO-COUPON BOND PRICING" in summary and "Q2: THETA RECOVERY & OPTION PRICING" in summary and "Q3: SENSITIVITY ANALYSIS" in summary
+
+
+def test_exact_market_and_reference_stepper_flags(built, tmp_path):
+    r = _run("q2", tmp_path, "--paths-log2", "16", "--seed", "3", "--market", "exact", "--stepper", "reference",
+             "--precision", "f32", "--no")
+    assert "Market curve: exact" in r.stdout and "ZBC (control variate adjusted):" in r.stdout

@@ -219,7 +219,9 @@ def test_zcb_curve_vs_oracle(setup, hwmc_mod, golden, precision):
     # sharding + reproducibility
     whole = e.simulate_zcb(5000, 21)
     parts = e.simulate_zcb(2000, 21) + e.simulate_zcb(3000, 21, path_offset=2000)
-    np.testing.assert_allclose(whole[1:], parts[1:], rtol=1e-13)
+    # float32 engine: the 64 lanes of a wave are summed in float32 before going to double, so a
+    # different grouping of pairs into waves moves the sum by float rounding; float64: exact.
+    np.testing.assert_allclose(whole[1:], parts[1:], rtol=1e-6 if precision == "f32" else 1e-13)
     assert np.array_equal(whole, e.simulate_zcb(5000, 21))
 
 

@@ -1,0 +1,164 @@
+// loop_lab.hip -- ablation of the path kernel's inner loop on the GPU it runs on: which part of
+// {Philox4x32-10, Box-Muller, OU step} costs what, against the issue-cost model built from
+// tools/valu_rates.hip.  All variants run interleaved in one process (rule: A/B in one binary).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I <pkg>/csrc tools/loop_lab.hip -o tools/bin/loop_lab
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "hw_kernels.hpp"
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+using namespace hwk;
+
+// Philox block with the round keys and/or the two multipliers forced into VGPRs (VK, VM) to test
+// whether SGPR / literal operands cost issue cycles in this instruction mix.
+struct VKeys { uint32_t k0[10], k1[10], m0, m1; };
+template <bool VK, bool VM>
+__device__ __forceinline__ void philox_block_v(const PhiloxKey& k, const VKeys& vk, const PhiloxPath& pp, uint32_t j,
+                                               uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
+{
+    const uint32_t M0 = VM ? vk.m0 : kM0, M1 = VM ? vk.m1 : kM1;
+    uint32_t hi0, lo0, hi1, lo1;
+    mulhilo(kM0, j, hi0, lo0);
+    uint32_t c2 = pp.A2 ^ hi0;
+    uint32_t c3 = lo0;
+    mulhilo(M1, c2, hi1, lo1);
+    uint32_t c0 = hi1 ^ pp.Q;
+    uint32_t c1 = lo1;
+    c2 = pp.R ^ c3;
+    mulhilo(M0, c0, hi0, lo0);
+    mulhilo(M1, c2, hi1, lo1);
+    c0 = hi1 ^ c1 ^ (VK ? vk.k0[2] : k.k0[2]);
+    c1 = lo1;
+    c2 = hi0 ^ pp.T;
+    c3 = lo0;
+#pragma unroll
+    for (int r = 3; r < 10; r++) {
+        mulhilo(M0, c0, hi0, lo0);
+        mulhilo(M1, c2, hi1, lo1);
+        c0 = hi1 ^ c1 ^ (VK ? vk.k0[r] : k.k0[r]);
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ (VK ? vk.k1[r] : k.k1[r]);
+        c3 = lo0;
+    }
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+__device__ __forceinline__ uint32_t to_vgpr(uint32_t x)
+{
+    uint32_t v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+    return v;
+}
+
+// MODE 0: Philox only   1: Philox + Box-Muller   2: Philox + BM + OU step (the real loop)
+// MODE 3: BM + step on recycled bits (no Philox)  4: OU step only on recycled normals
+template <int MODE, int ILP, bool VK = false, bool VM = false>
+__global__ void __launch_bounds__(1024) lab_kernel(float* out, uint64_t seed, int nblk, int iters)
+{
+    const PhiloxKey key = philox_key(seed);
+    VKeys vk;
+    if (VK) for (int r = 0; r < 10; r++) { vk.k0[r] = to_vgpr(key.k0[r]); vk.k1[r] = to_vgpr(key.k1[r]); }
+    if (VM) { vk.m0 = to_vgpr(kM0 + (uint32_t)(seed >> 63)); vk.m1 = to_vgpr(kM1 + (uint32_t)(seed >> 63)); }
+    const int64_t T = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float sink = 0.0f;
+    for (int it = 0; it < iters; it++) {
+        PhiloxPath pp[ILP];
+        float y[ILP], S[ILP];
+        uint32_t acc[ILP];
+        uint32_t w0[ILP], w1[ILP], w2[ILP], w3[ILP];
+        for (int q = 0; q < ILP; q++) {
+            pp[q] = philox_path(key, (uint64_t)(t + (int64_t)(it * ILP + q) * T));
+            y[q] = 0; S[q] = 0; acc[q] = 0;
+            w0[q] = pp[q].A2; w1[q] = pp[q].Q; w2[q] = pp[q].R; w3[q] = pp[q].T;
+        }
+        for (int j = 0; j < nblk; j++) {
+#pragma unroll
+            for (int q = 0; q < ILP; q++) {
+                if (MODE <= 2) {
+                    if (VK || VM) philox_block_v<VK, VM>(key, vk, pp[q], (uint32_t)j, w0[q], w1[q], w2[q], w3[q]);
+                    else philox_block(key, pp[q], (uint32_t)j, w0[q], w1[q], w2[q], w3[q]);
+                }
+                if (MODE == 0) { acc[q] += (w0[q] ^ w1[q]) + (w2[q] ^ w3[q]); continue; }
+                float g[4];
+                if (MODE <= 3) {
+                    box_muller(w0[q], w1[q], g[0], g[1]);
+                    box_muller(w2[q], w3[q], g[2], g[3]);
+                } else {
+                    g[0] = __uint_as_float(w0[q]); g[1] = __uint_as_float(w1[q]);
+                    g[2] = __uint_as_float(w2[q]); g[3] = __uint_as_float(w3[q]);
+                }
+                if (MODE == 1) { S[q] += (g[0] + g[1]) + (g[2] + g[3]); continue; }
+#pragma unroll
+                for (int c = 0; c < 4; c++) { y[q] = __builtin_fmaf(y[q], 0.99f, g[c]); S[q] += y[q]; }
+                if (MODE == 3) {   // recycle bits cheaply so inputs keep changing: 4 full-rate ops
+                    w0[q] += 0x9E3779B9u; w1[q] ^= w0[q]; w2[q] += 0xBB67AE85u; w3[q] ^= w2[q];
+                }
+            }
+        }
+        for (int q = 0; q < ILP; q++) sink += S[q] + y[q] + (float)acc[q];
+    }
+    if (sink == 1.2345e-33f) out[t] = sink;
+}
+
+typedef void (*kern_t)(float*, uint64_t, int, int);
+struct Variant { const char* name; kern_t fn; int ilp; double model_cycles; };
+
+int main(int argc, char** argv)
+{
+    CHECK(hipSetDevice(0));
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    const int block = argc > 1 ? atoi(argv[1]) : 256;
+    const int waves_per_simd = argc > 2 ? atoi(argv[2]) : 8;
+    const int grid = cus * 4 * waves_per_simd / (block / 64);
+    const int nblk = 125, iters = 4;
+    float* d_out;
+    CHECK(hipMalloc(&d_out, (size_t)grid * block * sizeof(float)));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    // issue-cost model per 4-step block (cycles per wave per SIMD), measured rates: full 2.42, half 4.2, quarter 8.14
+    const double F = 2.42, H = 4.2, Q = 8.14;
+    const double philox = 17 * H + 34 * F, bm = 4 * H + 4 * F + 8 * Q + 6 * F, step = 9 * F;
+    Variant v[] = {
+        {"philox only        ", lab_kernel<0, 1>, 1, philox + 4 * F},
+        {"philox+BM          ", lab_kernel<1, 1>, 1, philox + bm + 4 * F},
+        {"philox+BM+step     ", lab_kernel<2, 1>, 1, philox + bm + step},
+        {"BM+step (no philox)", lab_kernel<3, 1>, 1, bm + step + 4 * F},
+        {"step only          ", lab_kernel<4, 1>, 1, step},
+        {"philox+BM+step ilp2", lab_kernel<2, 2>, 2, philox + bm + step},
+        {"philox only    ilp2", lab_kernel<0, 2>, 2, philox + 4 * F},
+        {"philox only  VK     ", lab_kernel<0, 1, true, false>, 1, philox + 4 * F},
+        {"philox only  VM     ", lab_kernel<0, 1, false, true>, 1, philox + 4 * F},
+        {"philox only  VK+VM  ", lab_kernel<0, 1, true, true>, 1, philox + 4 * F},
+        {"full         VK+VM  ", lab_kernel<2, 1, true, true>, 1, philox + bm + step},
+    };
+    const int nv = sizeof(v) / sizeof(v[0]);
+    std::vector<std::vector<float>> ms(nv);
+    for (int round = 0; round < 8; round++)
+        for (int k = 0; k < nv; k++) {
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(v[k].fn, dim3(grid), dim3(block), 0, 0, d_out, 1234ull + round, nblk, iters / v[k].ilp);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float t;
+            CHECK(hipEventElapsedTime(&t, e0, e1));
+            if (round >= 2) ms[k].push_back(t);
+        }
+    printf("device %s CUs=%d block=%d waves/SIMD=%d grid=%d  (%d Philox blocks x %d path-iterations per thread)\n",
+           prop.gcnArchName, cus, block, waves_per_simd, grid, nblk, iters);
+    printf("%-20s %9s %9s %12s %12s %8s\n", "variant", "min ms", "med ms", "cyc/block@2.4G", "model cyc", "ratio");
+    for (int k = 0; k < nv; k++) {
+        std::sort(ms[k].begin(), ms[k].end());
+        const double tmin = ms[k][0], tmed = ms[k][ms[k].size() / 2];
+        const double wave_blocks = (double)grid * (block / 64) * nblk * iters;
+        const double cyc = tmin * 1e-3 * 2.4e9 * (cus * 4.0) / wave_blocks;
+        printf("%-20s %9.4f %9.4f %12.1f %12.1f %8.3f\n", v[k].name, tmin, tmed, cyc, v[k].model_cycles, cyc / v[k].model_cycles);
+    }
+    return 0;
+}

@@ -66,6 +66,24 @@ DEFINE_KERNEL(k_add_f64, DECL_D, INIT_D, asm volatile("v_add_f64 %0, %0, %1" : "
 DEFINE_KERNEL(k_pk_fma_f32, DECL_D, INIT_D, asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(v[c]) : "v"(k1), "v"(k2)), SINK_D)
 DEFINE_KERNEL(k_pk_add_f32, DECL_D, INIT_D, asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(v[c]) : "v"(k2)), SINK_D)
 
+// operand-shape variants: does an SGPR / literal source, or a destination different from the
+// sources, change the issue cost?
+#define DECL_U2 unsigned v[kChains], t[kChains]; unsigned k1 = 0xD2511F53u, k2 = 0x9E3779B9u
+#define INIT_U2 for (int c = 0; c < kChains; c++) { v[c] = threadIdx.x * 2654435761u + c + seed; t[c] = 0; }
+#define XOR_3REG { asm volatile("v_xor_b32 %0, %1, %2" : "=&v"(t[c]) : "v"(v[c]), "v"(k1)); asm volatile("v_xor_b32 %0, %1, %2" : "=&v"(v[c]) : "v"(t[c]), "v"(k2)); }
+DEFINE_KERNEL(k_xor_3reg_x2, DECL_U2, INIT_U2, XOR_3REG, SINK_U)
+#define DECL_US unsigned v[kChains]; unsigned k1 = seed * 3u + 0xD2511F53u
+DEFINE_KERNEL(k_xor_sgpr, DECL_US, INIT_U, asm volatile("v_xor_b32 %0, %1, %0" : "+v"(v[c]) : "s"(k1)), SINK_U)
+DEFINE_KERNEL(k_xor_literal, DECL_U, INIT_U, asm volatile("v_xor_b32 %0, 0x9E3779B9, %0" : "+v"(v[c])), SINK_U)
+#define MAD64S { unsigned long long d; asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(v[c]), "s"(k1) : "vcc"); v[c] = (unsigned)(d >> 32); }
+DEFINE_KERNEL(k_mad_u64_sgpr, DECL_US, INIT_U, MAD64S, SINK_U)
+#define MAD64X { unsigned long long d; asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(v[c]), "s"(k1) : "vcc"); v[c] = (unsigned)(d >> 32) ^ (unsigned)d; }
+DEFINE_KERNEL(k_mad_u64_then_xor, DECL_US, INIT_U, MAD64X, SINK_U)
+DEFINE_KERNEL(k_fmamk_literal, DECL_F, INIT_F, asm volatile("v_fmamk_f32 %0, %0, 0x2f800000, %1" : "+v"(v[c]) : "v"(k2)), SINK_F)
+DEFINE_KERNEL(k_mul_literal, DECL_F, INIT_F, asm volatile("v_mul_f32 %0, 0x3f800001, %0" : "+v"(v[c])), SINK_F)
+#define DECL_FS float v[kChains]; float k1 = 1.0000001f + (float)seed * 1e-12f
+DEFINE_KERNEL(k_fmac_sgpr, DECL_FS, INIT_F, asm volatile("v_fmac_f32 %0, %1, %0" : "+v"(v[c]) : "s"(k1)), SINK_F)
+
 typedef void (*kern_t)(unsigned*, int, unsigned);
 
 struct Entry { const char* name; kern_t fn; };
@@ -95,6 +113,9 @@ int main(int argc, char** argv)
         {"v_xor_b32", k_xor_b32}, {"v_add_u32", k_add_u32}, {"v_mul_lo_u32", k_mul_lo_u32}, {"v_mul_hi_u32", k_mul_hi_u32},
         {"v_mad_u64_u32", k_mad_u64_u32}, {"v_mul_u32_u24", k_mul_u32_u24}, {"v_mul_hi_u32_u24", k_mul_hi_u32_u24},
         {"v_mad_u32_u24", k_mad_u32_u24},
+        {"xor d!=a!=b (x2)", k_xor_3reg_x2}, {"xor sgpr,v", k_xor_sgpr}, {"xor literal,v", k_xor_literal},
+        {"mad_u64 v*sgpr", k_mad_u64_sgpr}, {"mad_u64+xor(hi,lo)", k_mad_u64_then_xor},
+        {"fmamk literal", k_fmamk_literal}, {"mul literal", k_mul_literal}, {"fmac sgpr", k_fmac_sgpr},
     };
     printf("grid=%d blocks x %d threads (%d waves/SIMD), %d iters x %d instr/thread\n", grid, block, waves_per_simd, iters,
            kChains * kUnroll);
