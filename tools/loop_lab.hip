@@ -46,6 +46,37 @@ __device__ __forceinline__ void philox_block_v(const PhiloxKey& k, const VKeys& 
     }
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
+// Philox block with every full round written as one asm statement: 2 v_mad_u64_u32 into fresh
+// (early-clobber) register pairs, then 4 xors.  Same arithmetic as philox_block().
+__device__ __forceinline__ void philox_round_asm(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1)
+{
+    uint64_t p0, p1;
+    uint32_t m0 = kM0, m1 = kM1;
+    asm volatile("v_mad_u64_u32 %0, vcc, %2, %4, 0\n\tv_mad_u64_u32 %1, vcc, %3, %5, 0"
+                 : "=&v"(p0), "=&v"(p1) : "v"(c0), "v"(c2), "s"(m0), "s"(m1) : "vcc");
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    uint32_t n0, n2;
+    asm volatile("v_xor_b32 %0, %2, %3\n\tv_xor_b32 %1, %4, %5\n\tv_xor_b32 %0, %6, %0\n\tv_xor_b32 %1, %7, %1"
+                 : "=&v"(n0), "=&v"(n2) : "v"(hi1), "v"(c1), "v"(hi0), "v"(c3), "s"(k0), "s"(k1));
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+}
+__device__ __forceinline__ void philox_block_asm(const PhiloxKey& k, const PhiloxPath& pp, uint32_t j,
+                                                 uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
+{
+    uint32_t hi0, lo0, hi1, lo1;
+    mulhilo(kM0, j, hi0, lo0);
+    uint32_t c2 = pp.A2 ^ hi0;
+    uint32_t c3 = lo0;
+    mulhilo(kM1, c2, hi1, lo1);
+    uint32_t c0 = hi1 ^ pp.Q;
+    uint32_t c1 = lo1;
+    c2 = pp.R ^ c3;
+    c3 = pp.L0;
+#pragma unroll
+    for (int r = 2; r < 10; r++) philox_round_asm(c0, c1, c2, c3, k.k0[r], k.k1[r]);
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+
 __device__ __forceinline__ uint32_t to_vgpr(uint32_t x)
 {
     uint32_t v;
@@ -55,7 +86,7 @@ __device__ __forceinline__ uint32_t to_vgpr(uint32_t x)
 
 // MODE 0: Philox only   1: Philox + Box-Muller   2: Philox + BM + OU step (the real loop)
 // MODE 3: BM + step on recycled bits (no Philox)  4: OU step only on recycled normals
-template <int MODE, int ILP, bool VK = false, bool VM = false>
+template <int MODE, int ILP, bool VK = false, bool VM = false, bool ASM = false, int SYNC = 0>
 __global__ void __launch_bounds__(1024) lab_kernel(float* out, uint64_t seed, int nblk, int iters)
 {
     const PhiloxKey key = philox_key(seed);
@@ -76,10 +107,13 @@ __global__ void __launch_bounds__(1024) lab_kernel(float* out, uint64_t seed, in
             w0[q] = pp[q].A2; w1[q] = pp[q].Q; w2[q] = pp[q].R; w3[q] = pp[q].T;
         }
         for (int j = 0; j < nblk; j++) {
+            if (SYNC == 1) __builtin_amdgcn_s_barrier();                       // keep the workgroup's waves in phase
+            if (SYNC == 2 && (j & 3) == 0) __builtin_amdgcn_s_barrier();
 #pragma unroll
             for (int q = 0; q < ILP; q++) {
                 if (MODE <= 2) {
-                    if (VK || VM) philox_block_v<VK, VM>(key, vk, pp[q], (uint32_t)j, w0[q], w1[q], w2[q], w3[q]);
+                    if (ASM) philox_block_asm(key, pp[q], (uint32_t)j, w0[q], w1[q], w2[q], w3[q]);
+                    else if (VK || VM) philox_block_v<VK, VM>(key, vk, pp[q], (uint32_t)j, w0[q], w1[q], w2[q], w3[q]);
                     else philox_block(key, pp[q], (uint32_t)j, w0[q], w1[q], w2[q], w3[q]);
                 }
                 if (MODE == 0) { acc[q] += (w0[q] ^ w1[q]) + (w2[q] ^ w3[q]); continue; }
@@ -137,6 +171,11 @@ int main(int argc, char** argv)
         {"philox only  VM     ", lab_kernel<0, 1, false, true>, 1, philox + 4 * F},
         {"philox only  VK+VM  ", lab_kernel<0, 1, true, true>, 1, philox + 4 * F},
         {"full         VK+VM  ", lab_kernel<2, 1, true, true>, 1, philox + bm + step},
+        {"full  barrier/block ", lab_kernel<2, 1, false, false, false, 1>, 1, philox + bm + step},
+        {"full  barrier/4blk  ", lab_kernel<2, 1, false, false, false, 2>, 1, philox + bm + step},
+        {"philox only  asm rnd", lab_kernel<0, 1, false, false, true>, 1, philox + 4 * F},
+        {"philox asm   ilp2   ", lab_kernel<0, 2, false, false, true>, 2, philox + 4 * F},
+        {"full         asm rnd", lab_kernel<2, 1, false, false, true>, 1, philox + bm + step},
     };
     const int nv = sizeof(v) / sizeof(v[0]);
     std::vector<std::vector<float>> ms(nv);
