@@ -33,6 +33,10 @@ VALU_MODEL = {
     "superposed": {"full": 53, "half": 21, "quarter": 8},   # 34 xor,4 fmamk,6 mul,4 fmac,4 add,1 mov | 17 mad_u64,4 cvt | 2 log,2 sqrt,2 sin,2 cos
     "reference": {"full": 81, "half": 21, "quarter": 8},    # + per-step: sG mul, 2 add, 2 fma, 2 add, 2 mul/fma pairs on two legs
 }
+# Issue costs measured on MI355X at 8 waves/SIMD (tools/valu_rates.hip, tools/valu_patterns.hip; profiles/):
+# "full-rate" ops sustain one per 2.3 cycles (two waves issue side by side; one wave alone: 4.7),
+# v_mad_u64_u32 4.45, v_cvt_f32_u32 4.24, transcendentals 8.1.  The nominal 2/4/8 model is unreachable.
+MEASURED_ISSUE = {"full": 2.3, "half": 4.4, "quarter": 8.1}
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 V100_PUBLISHED_MPATHS = 1064.0  # BASELINE.md section 1 (reference README.md:44,162; one V100)
 
@@ -94,10 +98,19 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    # Rehearsal mode for a box with fewer GPUs than ranks (HWMC_BENCH_REHEARSAL=1): every rank uses
+    # device 0 and the all-reduce goes through gloo on the host.  It exercises the N>1 control flow
+    # only; its numbers are NOT a benchmark.  The real path is nccl (= RCCL) with one GPU per rank.
+    rehearsal = os.environ.get("HWMC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import numpy as np
     import hwmc
@@ -121,14 +134,29 @@ def main():
     offset, shard_n = hwmc.parallel.shard(n_pairs * world, rank, world)
     assert shard_n == n_pairs
 
+    class _Done:
+        def wait(self):
+            return None
+
     def step(i, seed):
         e.enqueue_ZBC(out[i].data_ptr(), n_pairs, seed, path_offset=offset, stepper=stepper, stream=stream)
+        if rehearsal and world > 1:                                     # host round trip, synchronous
+            side.synchronize()
+            tmp = out[i].cpu()
+            dist.all_reduce(tmp)
+            out[i].copy_(tmp)
+            return _Done()
         return hwmc.parallel.allreduce_sums(out[i], async_op=True)     # None in a single process
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if world > 1:                                                      # build the communicator outside any timed region
+        warm = torch.zeros(5, dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(warm)
+        fence()
 
     t_spin = time.perf_counter()
     while (time.perf_counter() - t_spin) * 1e3 < a.spinup_ms:      # untimed: bring the clocks up
@@ -160,18 +188,19 @@ def main():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     region_ms = ev0.elapsed_time(ev1)
+    sums = out[W:].cpu().numpy()                           # the K all-reduced moment vectors of the timed steps
     e.profile_enable(K)                                    # untimed pass: isolated per-launch durations
+    scratch = torch.zeros(5, dtype=torch.float64, device=dev)
     for i in range(K):
-        e.enqueue_ZBC(out[W + i].data_ptr(), n_pairs, 1234 + 12345 * i, path_offset=offset, stepper=stepper, stream=stream)
+        e.enqueue_ZBC(scratch.data_ptr(), n_pairs, 1234 + 12345 * i, path_offset=offset, stepper=stepper, stream=stream)
     torch.cuda.synchronize()
     kernel_ms = e.profile_read(K)
     clock_mhz = e.profile_clock_mhz() if a.stepper == "superposed" else None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    sums = out[W:].cpu().numpy()
     if rank == 0:
         n_total = 2 * n_pairs * world
         prices = [hwmc.cv_price(s, n_total, float(P[-1])) for s in sums]
@@ -184,11 +213,19 @@ def main():
         geo_blocks = min((n_pairs + 255) // 256, info["compute_units"] * 8)
         algo_bytes = geo_blocks * 5 * 8 + 5 * 8            # partial rows written + the 5 sums (stateless Philox: no state traffic)
         achieved = algo_bytes / (kavg * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc) and a.stepper == "superposed" and a.paths_log2 == 20 and a.grid_steps == 1000:
+            with open(pmc) as fh:
+                traffic = json.load(fh)["hbm_traffic_bytes_per_launch"]["corrected_bytes"]
+            traffic_src = "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH_SIZE x2 on gfx950)"
         vm = VALU_MODEL[a.stepper]
         cyc_per_block = 2 * vm["full"] + 4 * vm["half"] + 8 * vm["quarter"]
         waves = (n_pairs + 63) // 64
         simd_cycles = waves * (steps_exec / 4.0) * cyc_per_block
         valu_frac = simd_cycles / (info["compute_units"] * 4 * info["clock_mhz"] * 1e6 * kavg * 1e-3)
+        cyc_meas = sum(MEASURED_ISSUE[k] * vm[k] for k in vm)
+        achieved_cyc = kavg * 1e-3 * (clock_mhz or info["clock_mhz"]) * 1e6 * info["compute_units"] * 4 / (waves * steps_exec / 4.0)
         line = {
             "metric": "M paths/sec (ZBC option, 1000 steps)", "value": round(value, 2), "unit": "M paths/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 5),
@@ -207,17 +244,22 @@ def main():
             "price_mean": st["mean"], "ci95_width": st["ci95_width"], "ci95_halfwidth_single_run": prices[0]["ci95_halfwidth"],
             "beta_mean": float(np.mean([r["beta"] for r in prices])),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "zbc_%s_kernel" % a.stepper, "kernel_ms_avg": kavg, "kernel_ms_per_launch_events": {"avg": float(np.mean(kernel_ms)), "min": float(np.min(kernel_ms))},
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "stateless Philox: the path kernel has ~0 algorithmic HBM traffic; the binding roof is VALU issue (see valu)"},
             "valu": {"bound": "valu-issue", "issue_cycles_per_wave_per_4_steps": cyc_per_block,
                      "instr_per_4_steps": vm, "clock_mhz_nominal": info["clock_mhz"], "frac_of_nominal_clock_peak": valu_frac,
                      "clock_mhz_in_kernel": clock_mhz,
-                     "frac_at_measured_clock": (valu_frac * info["clock_mhz"] / clock_mhz) if clock_mhz else None},
+                     "frac_at_measured_clock": (valu_frac * info["clock_mhz"] / clock_mhz) if clock_mhz else None,
+                     "measured_issue_cycles_per_op": MEASURED_ISSUE, "issue_cycles_per_4_steps_at_measured_rates": cyc_meas,
+                     "achieved_cycles_per_wave_per_4_steps": achieved_cyc, "frac_of_measured_rate_ceiling": cyc_meas / achieved_cyc},
             "kernel_Mpaths_per_sec": (2 * n_pairs / kavg) / 1000.0,
             "device": info["name"],
         }
+        if rehearsal:
+            line["rehearsal"] = "gloo, all ranks on device 0 -- control-flow check only, not a measurement"
+        assert 0.0 < st["mean"] < 0.1 and all(np.isfinite(s).all() for s in sums), "implausible reduced sums"
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(P, f, a.profile, a.grid_steps, a.cpu_seconds)
         print(json.dumps(line))

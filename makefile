@@ -5,7 +5,7 @@ CXX   ?= g++
 PKG   = monte-carlo-simulation-of-hull-white-model-and-sensitivities-computation_amd
 LIB   = $(PKG)/libhw_hip.so
 CXXFLAGS = -O2 -std=c++17 -Wall -Wextra -I include
-LDFLAGS  = -L$(PKG) -lhw_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)'
+LDFLAGS  = -pthread -L$(PKG) -lhw_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)'
 SRC = src
 BIN = bin
 # the reference pins CUDA_VISIBLE_DEVICES=2 (makefile:27); here the device is a flag: make run-q1 ARGS="--device 2"

@@ -67,6 +67,7 @@ struct hw_ctx {
     int max_blocks_per_cu = 0;        // in units of block_size-thread workgroups; 0 = default
     int table_in_lds = 0;
     int ilp = 1;
+    int single_launch = 0;            // 0: path kernel + column pass; 1: in-kernel sharded-ticket finish
     // optional per-launch event pairs around the path kernel (hw_profile_enable)
     std::vector<hipEvent_t> prof_ev;
     int prof_used = 0, prof_cap = 0;
@@ -117,6 +118,16 @@ Geometry geometry(const hw_ctx* c, int64_t n_units, int ilp)
     g.iters = (int)((n_units + per_iter - 1) / per_iter);
     if (g.iters < 1) g.iters = 1;
     return g;
+}
+
+// second launch of the default two-launch finish (no-op when the kernel finished in-launch)
+int finish_columns(hw_ctx* c, hipStream_t st, int rows, int ncol, double* d_out)
+{
+    if (c->single_launch) return HW_OK;
+    hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(ncol), dim3(256), 0, st, (const double*)c->d_partials, rows, ncol,
+                       (const double*)nullptr, -1.0, d_out);
+    HIP_TRY(hipGetLastError());
+    return HW_OK;
 }
 
 struct Scenario {
@@ -191,14 +202,15 @@ int launch_zbc_superposed(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, co
     a.e = (REAL)sc[0].k.e;
     for (int k = 0; k < NSCEN; k++) a.sc[k] = make_scen<REAL>(sc[k], r->K);
     a.clk = c->prof_cap > 0 ? c->d_clk : nullptr;
+    unsigned* tk = c->single_launch ? c->d_ticket : nullptr;
     prof_mark(c, st, 0);
     if (ilp == 2)
-        hipLaunchKernelGGL((hwk::zbc_superposed_kernel<REAL, NSCEN, 2>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials, c->d_ticket, d_out);
+        hipLaunchKernelGGL((hwk::zbc_superposed_kernel<REAL, NSCEN, 2>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials, tk, d_out);
     else
-        hipLaunchKernelGGL((hwk::zbc_superposed_kernel<REAL, NSCEN, 1>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials, c->d_ticket, d_out);
+        hipLaunchKernelGGL((hwk::zbc_superposed_kernel<REAL, NSCEN, 1>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials, tk, d_out);
     prof_mark(c, st, 1);
     HIP_TRY(hipGetLastError());
-    return HW_OK;
+    return finish_columns(c, st, g.grid, 5 * NSCEN, d_out);
 }
 
 int launch_zbc_reference(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, const Scenario& s,
@@ -223,17 +235,18 @@ int launch_zbc_reference(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, con
     a.A = (float)s.A;
     a.B = (float)s.B;
     a.K = (float)r->K;
+    unsigned* tk = c->single_launch ? c->d_ticket : nullptr;
     prof_mark(c, st, 0);
     if (c->table_in_lds)
         hipLaunchKernelGGL(hwk::zbc_reference_kernel<1>, dim3(g.grid), dim3(g.block),
                            (size_t)n_steps_S1 * sizeof(float), st, a, (const float*)c->d_drift, c->d_partials,
-                           c->d_ticket, d_out);
+                           tk, d_out);
     else
         hipLaunchKernelGGL(hwk::zbc_reference_kernel<0>, dim3(g.grid), dim3(g.block), 0, st, a,
-                           (const float*)c->d_drift, c->d_partials, c->d_ticket, d_out);
+                           (const float*)c->d_drift, c->d_partials, tk, d_out);
     prof_mark(c, st, 1);
     HIP_TRY(hipGetLastError());
-    return HW_OK;
+    return finish_columns(c, st, g.grid, 5, d_out);
 }
 
 int zbc_enqueue(hw_ctx* c, const hw_zbc_request* r, int n_scen, const double* sigma,
@@ -337,14 +350,15 @@ int launch_vega(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset,
     a.cD = (REAL)cD[n_steps_S1];
     a.s_over_sigma = (REAL)(s.k.sig_st / p.sigma);
     a.zs = (REAL)(s.k.dt * s.k.sig_st / p.sigma);
+    unsigned* tk = c->single_launch ? c->d_ticket : nullptr;
     prof_mark(c, st, 0);
     if (ilp == 2)
-        hipLaunchKernelGGL((hwk::vega_pathwise_kernel<REAL, 2>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials, c->d_ticket, d_out);
+        hipLaunchKernelGGL((hwk::vega_pathwise_kernel<REAL, 2>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials, tk, d_out);
     else
-        hipLaunchKernelGGL((hwk::vega_pathwise_kernel<REAL, 1>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials, c->d_ticket, d_out);
+        hipLaunchKernelGGL((hwk::vega_pathwise_kernel<REAL, 1>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials, tk, d_out);
     prof_mark(c, st, 1);
     HIP_TRY(hipGetLastError());
-    return HW_OK;
+    return finish_columns(c, st, g.grid, 1, d_out);
 }
 
 // run `enqueue(d_out, stream)` on the context stream between events, copy n doubles back
@@ -434,8 +448,9 @@ int hw_create(const hw_params* p, int device, hw_ctx** out)
     if (e == hipSuccess) e = hipMalloc(&c->d_drift, (size_t)p->n_steps * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->d_clk, 64);
     if (e == hipSuccess) e = hipMemset(c->d_clk, 0, 64);
-    if (e == hipSuccess) e = hipMalloc(&c->d_ticket, 64);
-    if (e == hipSuccess) e = hipMemset(c->d_ticket, 0, 64);
+    if (e == hipSuccess) e = hipMalloc(&c->d_ticket, 9 * hwk::kTicketStride * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(c->d_ticket, 0, 9 * hwk::kTicketStride * sizeof(unsigned));
+    if (const char* m = getenv("HWMC_SINGLE_LAUNCH")) c->single_launch = atoi(m) ? 1 : 0;
     if (e != hipSuccess) {
         hw_destroy(c);
         return fail(HW_E_HIP, "hw_create: %s", hipGetErrorString(e));

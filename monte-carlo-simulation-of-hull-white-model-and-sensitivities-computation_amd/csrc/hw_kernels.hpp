@@ -186,20 +186,29 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
-// Single-launch finish of a sum over the whole grid: every workgroup stores its row of N partial
-// sums, then takes a ticket; the workgroup that draws the last ticket sums all rows in a FIXED
-// order (rows strided over threads, lane tree, waves in index order) and writes out[0..N), so the
-// result is bit-reproducible whichever workgroup happens to finish last.  Inter-workgroup
-// visibility follows the agent-scope release/acquire recipe: stores -> s_waitcnt vmcnt(0) ->
-// release fence -> s_waitcnt vmcnt(0) -> relaxed agent atomic; the last workgroup: acquire fence
-// by one lane -> s_waitcnt vmcnt(0) -> barrier -> plain loads.  The last workgroup re-arms the
-// ticket counter for the next launch on the stream.
+// Finish of a sum over the whole grid.  Every workgroup reduces its threads' N values (lane tree,
+// waves in index order) and stores one row of partials.  What happens next is chosen by the host
+// through the `ticket` argument:
+//   ticket == nullptr : nothing more here; the host launches finalize_columns_kernel (the kernel
+//                       boundary publishes the rows).  Default: simplest and, measured, fastest.
+//   ticket != nullptr : single launch.  Rows are written with 8-byte agent-scope atomic stores
+//                       (write-through, no release fence needed), the storing wave drains them
+//                       (s_waitcnt vmcnt(0)), lane 0 takes a ticket on one of 8 sharded counters
+//                       (blockIdx & 7, each on its own 128-B line); the last arriver of a shard takes
+//                       a ticket on the top counter, and the workgroup that completes the top counter
+//                       acquires (agent scope), reads all rows with agent-scope atomic loads, sums
+//                       them in a FIXED order and re-arms the counters.  [2048 arrivals on ONE counter
+//                       serialise at ~12 ns each = 25 us at the end of a 285 us kernel; sharding
+//                       brings that to ~3 us.]
+// Either way the order of the floating-point additions does not depend on timing: bit-reproducible.
+constexpr int kTicketStride = 32;     // unsigned words between counters (128 B)
+
 template <int N>
 __device__ __forceinline__ void grid_sum_finish(double (&v)[N], double* smem /*[kMaxWaves*N]*/,
                                                 double* __restrict__ partials, unsigned* __restrict__ ticket,
                                                 double* __restrict__ out)
 {
-    __shared__ unsigned s_ticket;
+    __shared__ unsigned s_last;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int nwaves = (blockDim.x + kWave - 1) >> 6;
 #pragma unroll
@@ -208,21 +217,33 @@ __device__ __forceinline__ void grid_sum_finish(double (&v)[N], double* smem /*[
         if (lane == 0) smem[wave * N + k] = s;
     }
     __syncthreads();
+    if (wave != 0 && ticket == nullptr) return;
     if (wave == 0) {
         if (lane < N) {
             double t = 0.0;
             for (int w = 0; w < nwaves; w++) t += smem[w * N + lane];
-            partials[(size_t)blockIdx.x * N + lane] = t;
+            double* dst = partials + (size_t)blockIdx.x * N + lane;
+            if (ticket == nullptr) *dst = t;
+            else __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(t),
+                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (ticket == nullptr) return;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave issued all the row's stores
         if (lane == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned r = blockIdx.x & 7u;
+            const unsigned n_sub = (gridDim.x - r + 7u) >> 3;      // workgroups with blockIdx & 7 == r
+            const unsigned n_groups = gridDim.x < 8u ? gridDim.x : 8u;
+            unsigned last = 0;
+            const unsigned t1 = __hip_atomic_fetch_add(ticket + (1 + r) * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t1 == n_sub - 1) {
+                const unsigned t2 = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = (t2 == n_groups - 1) ? 1u : 0u;
+            }
+            s_last = last;
         }
     }
     __syncthreads();
-    if (s_ticket != gridDim.x - 1) return;                         // workgroup-uniform
+    if (!s_last) return;                                           // workgroup-uniform
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -233,7 +254,11 @@ __device__ __forceinline__ void grid_sum_finish(double (&v)[N], double* smem /*[
     for (int k = 0; k < N; k++) acc[k] = 0.0;
     for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
 #pragma unroll
-        for (int k = 0; k < N; k++) acc[k] += partials[(size_t)b * N + k];
+        for (int k = 0; k < N; k++) {
+            const unsigned long long bits = __hip_atomic_load(reinterpret_cast<unsigned long long*>(partials + (size_t)b * N + k),
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc[k] += __longlong_as_double((long long)bits);
+        }
     }
 #pragma unroll
     for (int k = 0; k < N; k++) {
@@ -246,7 +271,7 @@ __device__ __forceinline__ void grid_sum_finish(double (&v)[N], double* smem /*[
         for (int w = 0; w < nwaves; w++) t += smem[w * N + threadIdx.x];
         out[threadIdx.x] = t;
     }
-    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 9) __hip_atomic_store(ticket + threadIdx.x * kTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Second (tiny) launch: out[k] = scale[k] * sum_b partials[b*ncol + k], fixed order.

@@ -27,6 +27,7 @@
 #include <ctime>
 #include <string>
 #include <sys/stat.h>
+#include <thread>
 #include <vector>
 
 #include "../include/hw_mc.h"
@@ -221,55 +222,64 @@ struct Fleet {
         *off = g * base + std::min<int64_t>(g, rem);
         *cnt = base + (g < rem ? 1 : 0);
     }
+    // Run fn(g, offset, count) for every device concurrently (one host thread per context, as the
+    // C ABI requires); with one device it runs inline.
+    template <typename F>
+    void for_each_device(int64_t n, F fn)
+    {
+        if (ctx.size() == 1) { fn(0, (int64_t)0, n); return; }
+        std::vector<std::thread> th;
+        for (size_t g = 0; g < ctx.size(); g++) {
+            int64_t off, cnt;
+            shard(n, (int)g, &off, &cnt);
+            th.emplace_back([=, &fn]() { fn((int)g, off, cnt); });
+        }
+        for (auto& t : th) t.join();
+    }
     // ZBC moments over n pairs (all devices), kernel time = slowest device
     void zbc(hw_zbc_request r, double out[5], float* ms)
     {
-        for (int k = 0; k < 5; k++) out[k] = 0.0;
-        float worst = 0.0f;
-        const int64_t n = r.n_pairs;
+        const size_t G = ctx.size();
+        std::vector<double> part(5 * G, 0.0);
+        std::vector<float> t(G, 0.0f);
+        std::vector<int> rc(G, 0);
         const uint64_t base_off = r.path_offset;
-        for (size_t g = 0; g < ctx.size(); g++) {
-            int64_t off, cnt;
-            shard(n, (int)g, &off, &cnt);
-            r.n_pairs = cnt;
-            r.path_offset = base_off + (uint64_t)off;
-            double part[5];
-            float t = 0.0f;
-            HW_CHECK(hw_zbc_moments(ctx[g], &r, part, &t));
-            for (int k = 0; k < 5; k++) out[k] += part[k];
-            worst = std::max(worst, t);
-        }
-        if (ms) *ms = worst;
+        for_each_device(r.n_pairs, [&](int g, int64_t off, int64_t cnt) {
+            hw_zbc_request q = r;
+            q.n_pairs = cnt;
+            q.path_offset = base_off + (uint64_t)off;
+            rc[g] = hw_zbc_moments(ctx[g], &q, &part[5 * g], &t[g]);
+        });
+        for (size_t g = 0; g < G; g++) if (rc[g] != HW_OK) die("hw_zbc_moments");
+        for (int k = 0; k < 5; k++) { out[k] = 0.0; for (size_t g = 0; g < G; g++) out[k] += part[5 * g + k]; }
+        if (ms) *ms = *std::max_element(t.begin(), t.end());
     }
     void zcb(int64_t n, uint64_t seed, double sigma, std::vector<double>* P_sum, float* ms)
     {
+        const size_t G = ctx.size();
+        std::vector<double> part((size_t)p.n_mat * G, 0.0);
+        std::vector<float> t(G, 0.0f);
+        std::vector<int> rc(G, 0);
+        for_each_device(n, [&](int g, int64_t off, int64_t cnt) {
+            rc[g] = hw_zcb_curve(ctx[g], cnt, seed, (uint64_t)off, sigma, &part[(size_t)p.n_mat * g], &t[g]);
+        });
+        for (size_t g = 0; g < G; g++) if (rc[g] != HW_OK) die("hw_zcb_curve");
         P_sum->assign(p.n_mat, 0.0);
-        float worst = 0.0f;
-        std::vector<double> part(p.n_mat);
-        for (size_t g = 0; g < ctx.size(); g++) {
-            int64_t off, cnt;
-            shard(n, (int)g, &off, &cnt);
-            float t = 0.0f;
-            HW_CHECK(hw_zcb_curve(ctx[g], cnt, seed, (uint64_t)off, sigma, part.data(), &t));
-            for (int j = 0; j < p.n_mat; j++) (*P_sum)[j] += part[j];
-            worst = std::max(worst, t);
-        }
-        if (ms) *ms = worst;
+        for (int j = 0; j < p.n_mat; j++) for (size_t g = 0; g < G; g++) (*P_sum)[j] += part[(size_t)p.n_mat * g + j];
+        if (ms) *ms = *std::max_element(t.begin(), t.end());
     }
     double vega(int64_t n, uint64_t seed, double S1, double S2, double K, float* ms)
     {
+        const size_t G = ctx.size();
+        std::vector<double> part(G, 0.0);
+        std::vector<float> t(G, 0.0f);
+        std::vector<int> rc(G, 0);
+        for_each_device(n, [&](int g, int64_t off, int64_t cnt) {
+            rc[g] = hw_vega_pathwise(ctx[g], cnt, seed, (uint64_t)off, S1, S2, K, 0, &part[g], &t[g]);
+        });
         double total = 0.0;
-        float worst = 0.0f;
-        for (size_t g = 0; g < ctx.size(); g++) {
-            int64_t off, cnt;
-            shard(n, (int)g, &off, &cnt);
-            double part = 0.0;
-            float t = 0.0f;
-            HW_CHECK(hw_vega_pathwise(ctx[g], cnt, seed, (uint64_t)off, S1, S2, K, 0, &part, &t));
-            total += part;
-            worst = std::max(worst, t);
-        }
-        if (ms) *ms = worst;
+        for (size_t g = 0; g < G; g++) { if (rc[g] != HW_OK) die("hw_vega_pathwise"); total += part[g]; }
+        if (ms) *ms = *std::max_element(t.begin(), t.end());
         return total;
     }
 };

@@ -130,6 +130,9 @@ def test_zbc_lds_table_variant_and_launch_knobs(setup, hwmc_mod):
             for st in (hwmc_mod.HW_STEPPER_SUPERPOSED, hwmc_mod.HW_STEPPER_REFERENCE):
                 got = e.simulate_ZBC_control_variate(n, 77, stepper=st)
                 np.testing.assert_allclose(got, want, rtol=REL_F32)
+            # the other two kernels under the same geometry (wave count per workgroup changes the LDS rows)
+            np.testing.assert_allclose(e.simulate_zcb(700, 5), o.zcb_curve(700, 5), rtol=REL_F32)
+            assert e.simulate_sensitivity(n, 9) == pytest.approx(o.vega_pathwise(P, f, n, 9), rel=REL_F32)
     finally:
         e.set_launch(256, 0, 0, 1)
 

@@ -86,9 +86,13 @@ __device__ __forceinline__ uint32_t to_vgpr(uint32_t x)
 
 // MODE 0: Philox only   1: Philox + Box-Muller   2: Philox + BM + OU step (the real loop)
 // MODE 3: BM + step on recycled bits (no Philox)  4: OU step only on recycled normals
-template <int MODE, int ILP, bool VK = false, bool VM = false, bool ASM = false, int SYNC = 0>
+template <int MODE, int ILP, bool VK = false, bool VM = false, bool ASM = false, int SYNC = 0, int EMODE = 0>
 __global__ void __launch_bounds__(1024) lab_kernel(float* out, uint64_t seed, int nblk, int iters)
 {
+    // EMODE: where the OU decay factor e lives: 0 literal, 1 SGPR (runtime-uniform), 2 VGPR
+    float e_s = 0.99f + (float)(seed >> 60) * 1e-9f;
+    float e_v = e_s;
+    if (EMODE == 2) asm volatile("v_mov_b32 %0, %1" : "=v"(e_v) : "s"(e_s));
     const PhiloxKey key = philox_key(seed);
     VKeys vk;
     if (VK) for (int r = 0; r < 10; r++) { vk.k0[r] = to_vgpr(key.k0[r]); vk.k1[r] = to_vgpr(key.k1[r]); }
@@ -127,7 +131,7 @@ __global__ void __launch_bounds__(1024) lab_kernel(float* out, uint64_t seed, in
                 }
                 if (MODE == 1) { S[q] += (g[0] + g[1]) + (g[2] + g[3]); continue; }
 #pragma unroll
-                for (int c = 0; c < 4; c++) { y[q] = __builtin_fmaf(y[q], 0.99f, g[c]); S[q] += y[q]; }
+                for (int c = 0; c < 4; c++) { y[q] = __builtin_fmaf(y[q], EMODE == 0 ? 0.99f : (EMODE == 1 ? e_s : e_v), g[c]); S[q] += y[q]; }
                 if (MODE == 3) {   // recycle bits cheaply so inputs keep changing: 4 full-rate ops
                     w0[q] += 0x9E3779B9u; w1[q] ^= w0[q]; w2[q] += 0xBB67AE85u; w3[q] ^= w2[q];
                 }
@@ -171,6 +175,8 @@ int main(int argc, char** argv)
         {"philox only  VM     ", lab_kernel<0, 1, false, true>, 1, philox + 4 * F},
         {"philox only  VK+VM  ", lab_kernel<0, 1, true, true>, 1, philox + 4 * F},
         {"full         VK+VM  ", lab_kernel<2, 1, true, true>, 1, philox + bm + step},
+        {"full  e in SGPR     ", lab_kernel<2, 1, false, false, false, 0, 1>, 1, philox + bm + step},
+        {"full  e in VGPR     ", lab_kernel<2, 1, false, false, false, 0, 2>, 1, philox + bm + step},
         {"full  barrier/block ", lab_kernel<2, 1, false, false, false, 1>, 1, philox + bm + step},
         {"full  barrier/4blk  ", lab_kernel<2, 1, false, false, false, 2>, 1, philox + bm + step},
         {"philox only  asm rnd", lab_kernel<0, 1, false, false, true>, 1, philox + 4 * F},
