@@ -42,10 +42,20 @@ run-q3: q3
 	@mkdir -p data plots
 	./$(BIN)/q3 $(ARGS)
 
+benchmark:
+	@mkdir -p tools/bin data plots
+	$(HIPCC) --offload-arch=gfx950 -O3 tools/valu_rates.hip -o tools/bin/valu_rates
+	$(HIPCC) --offload-arch=gfx950 -O3 tools/valu_patterns.hip -o tools/bin/valu_patterns
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -I $(PKG)/csrc tools/loop_lab.hip -o tools/bin/loop_lab
+
+run-benchmark: benchmark lib
+	@mkdir -p data plots
+	python3 tools/benchmark_reductions.py
+
 run-all: run-q1 run-q2 run-q3
 
-analyze: run-all
-	@echo "run the reference's analyze.py against data/ (same file names and schemas)"
+analyze: run-all run-benchmark
+	@echo "data/ now holds every file the reference's analyze.py reads (same names and schemas)"
 
 oracle:
 	$(MAKE) -C oracle
@@ -56,4 +66,4 @@ clean:
 clean-all:
 	rm -rf $(BIN) data plots
 
-.PHONY: all lib oracle clean clean-all run-q1 run-q2 run-q3 run-all analyze
+.PHONY: all lib oracle benchmark run-benchmark clean clean-all run-q1 run-q2 run-q3 run-all analyze

@@ -253,6 +253,27 @@ class HullWhiteEngine:
         pp = cv_price(sp, 2 * n_pairs, P0S2)["price"]
         return {"p_minus": pm, "p_plus": pp, "vega_fd": (pp - pm) / (2.0 * epsilon)}
 
+    def run_finite_difference_recalibrated(self, n_pairs, seed, epsilon=0.001, path_offset=0, S1=5.0,
+                                           S2=10.0, K=None):
+        """The reference's diagnostic FD (3_sens:449-525): theta held fixed, the market curves
+        re-simulated at sigma -+ eps (simulate_zcb + compute_average_and_forward) and the option
+        priced on them with the base drift table.  Known to be ~2x off (README.md:51)."""
+        s0 = self.params.sigma
+        P_keep, f_keep = self.P, self.f
+        prices = []
+        try:
+            for sg in (s0 - epsilon, s0 + epsilon):
+                P_sum = self.simulate_zcb(n_pairs, seed, path_offset, sigma=sg)      # recompute_market_data
+                Ps, fs = self.compute_average_and_forward(P_sum, 2 * n_pairs)
+                self.load_market_data(Ps, fs)
+                sums = self.simulate_ZBC_control_variate(n_pairs, seed, path_offset, S1, S2, K, sigma=sg,
+                                                         drift_mode=L.HW_DRIFT_BASE)
+                prices.append(cv_price(sums, 2 * n_pairs, float(Ps[-1]))["price"])
+        finally:
+            self.load_market_data(P_keep, f_keep)                                    # 3_sens:516-520
+        return {"p_minus": prices[0], "p_plus": prices[1],
+                "vega_fd_recalibrated": (prices[1] - prices[0]) / (2.0 * epsilon)}
+
     def simulate_paths_show(self, n, seed, path_offset=0):
         out = np.zeros((n, self.params.n_steps + 1), np.float32)
         L.check(self.lib.hw_sample_paths(self._ctx, int(n), int(seed), int(path_offset), _fp(out)))

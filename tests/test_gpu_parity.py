@@ -281,6 +281,28 @@ def test_finite_difference_vega(setup, hwmc_mod, golden):
             np.testing.assert_allclose(sc[1], case["zbc_sums"], rtol=REL_F32)
 
 
+def test_finite_difference_recalibrated_vs_oracle(setup, hwmc_mod):
+    """run_finite_difference_recalibrated (3_sens:449-525): curves re-simulated at sigma -+ eps, then
+    the option priced on them -- the same sequence on the oracle."""
+    e, o, P, f = setup("head")
+    n, seed, eps = 1 << 13, 11, 1e-3
+    s0 = o.sigma
+    got = e.run_finite_difference_recalibrated(n, seed, eps)
+    want = []
+    for sg in (s0 - eps, s0 + eps):
+        Ps, fs = o.average_and_forward(o.zcb_curve(n, seed, sigma=sg), 2 * n)
+        sums = o.zbc_moments(Ps, fs, n, seed, sigma=sg)
+        want.append(o.cv_price(sums, 2 * n, float(Ps[-1]))["price"])
+    # f(0,S1) is a float32 difference of logs of the re-simulated curve (market_data.cuh:125): a
+    # 1e-7 relative difference in P_sum moves f by ~3e-5 relative and the price by ~1e-5 through A(t,T)
+    assert got["p_minus"] == pytest.approx(want[0], rel=1e-4)
+    assert got["p_plus"] == pytest.approx(want[1], rel=1e-4)
+    assert e.P is P or np.array_equal(e.P, P)                      # market restored
+    # the documented pathology: about twice the true Vega (README.md:51, SURVEY 6.2: 0.476 for 'head')
+    big = e.run_finite_difference_recalibrated(1 << 18, 5)
+    assert 0.3 < big["vega_fd_recalibrated"] < 0.7
+
+
 def test_sample_paths_vs_oracle(setup, golden):
     e, o, _, _ = setup("head")
     got = e.simulate_paths_show(32, 4242)
