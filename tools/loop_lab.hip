@@ -142,6 +142,56 @@ __global__ void __launch_bounds__(1024) lab_kernel(float* out, uint64_t seed, in
     if (sink == 1.2345e-33f) out[t] = sink;
 }
 
+// ---- second family: Box-Muller / loop-structure variants of the full loop -----------------------
+// BMV 0: rocRAND-exact Box-Muller (production).  BMV 1: the angle is taken from the top 23 bits of the word
+// placed in a [1,2) float (v_sin/v_cos are 1-periodic in revolutions): one v_alignbit replaces cvt+fma.
+// BMV 2: BMV 1 + radius as sqrt(-log2 u) with the constant sqrt(2 ln 2) folded into the caller.
+template <int BMV>
+__device__ __forceinline__ void bm_variant(uint32_t x, uint32_t y, float& n0, float& n1)
+{
+    constexpr float kInv = 2.3283064e-10f;
+    const float u = __builtin_fmaf((float)x, kInv, kInv);
+    float w;
+    if (BMV == 0) w = __builtin_fmaf((float)y, kInv, kInv);
+    else w = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, y, 9));       // 0x3F800000 | (y >> 9)
+    float s;
+    if (BMV == 2) s = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u));
+    else s = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u) * -1.3862943611198906f);
+    n0 = __builtin_amdgcn_sinf(w) * s;
+    n1 = __builtin_amdgcn_cosf(w) * s;
+}
+
+template <int BMV, int PIPE>
+__global__ void __launch_bounds__(1024) lab2_kernel(float* out, uint64_t seed, int nblk, int iters)
+{
+    const PhiloxKey key = philox_key(seed);
+    const int64_t T = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float sink = 0.0f;
+    for (int it = 0; it < iters; it++) {
+        const PhiloxPath pp = philox_path(key, (uint64_t)(t + (int64_t)it * T));
+        float y = 0, S = 0;
+        uint32_t w0, w1, w2, w3;
+        if (PIPE) philox_block(key, pp, 0u, w0, w1, w2, w3);
+        for (int j = 0; j < nblk; j++) {
+            uint32_t c0, c1, c2, c3;
+            if (PIPE) {                                   // words of block j are ready; start block j+1 now
+                c0 = w0; c1 = w1; c2 = w2; c3 = w3;
+                philox_block(key, pp, (uint32_t)(j + 1), w0, w1, w2, w3);
+            } else {
+                philox_block(key, pp, (uint32_t)j, c0, c1, c2, c3);
+            }
+            float g[4];
+            bm_variant<BMV>(c0, c1, g[0], g[1]);
+            bm_variant<BMV>(c2, c3, g[2], g[3]);
+#pragma unroll
+            for (int c = 0; c < 4; c++) { y = __builtin_fmaf(y, 0.99f, g[c]); S += y; }
+        }
+        sink += S + y + (PIPE ? (float)(w0 ^ w1 ^ w2 ^ w3) : 0.0f);
+    }
+    if (sink == 1.2345e-33f) out[t] = sink;
+}
+
 typedef void (*kern_t)(float*, uint64_t, int, int);
 struct Variant { const char* name; kern_t fn; int ilp; double model_cycles; };
 
@@ -179,6 +229,11 @@ int main(int argc, char** argv)
         {"full  e in VGPR     ", lab_kernel<2, 1, false, false, false, 0, 2>, 1, philox + bm + step},
         {"full  barrier/block ", lab_kernel<2, 1, false, false, false, 1>, 1, philox + bm + step},
         {"full  barrier/4blk  ", lab_kernel<2, 1, false, false, false, 2>, 1, philox + bm + step},
+        {"L2 baseline         ", lab2_kernel<0, 0>, 1, philox + bm + step},
+        {"L2 angle bits       ", lab2_kernel<1, 0>, 1, philox + bm + step},
+        {"L2 angle+sqrt(-log) ", lab2_kernel<2, 0>, 1, philox + bm + step},
+        {"L2 pipelined        ", lab2_kernel<0, 1>, 1, philox + bm + step},
+        {"L2 pipelined+tricks ", lab2_kernel<2, 1>, 1, philox + bm + step},
         {"philox only  asm rnd", lab_kernel<0, 1, false, false, true>, 1, philox + 4 * F},
         {"philox asm   ilp2   ", lab_kernel<0, 2, false, false, true>, 2, philox + 4 * F},
         {"full         asm rnd", lab_kernel<2, 1, false, false, true>, 1, philox + bm + step},
