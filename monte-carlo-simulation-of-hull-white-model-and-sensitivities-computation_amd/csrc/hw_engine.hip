@@ -308,6 +308,8 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
     a.e = (REAL)k.e;
     a.cz = (REAL)(k.dt * k.sig_st * kLog2e);
     const size_t lds = (size_t)(g.block / 64) * n_mat * sizeof(double);
+    if (lds > 64 * 1024)
+        return fail(HW_E_INVALID, "n_mat = %d needs %zu B of LDS per workgroup at block size %d (limit 65536): use a smaller block", n_mat, lds, g.block);
     prof_mark(c, st, 0);
     hipLaunchKernelGGL(hwk::zcb_curve_kernel<REAL>, dim3(g.grid), dim3(g.block), lds, st, a, c->d_partials);
     prof_mark(c, st, 1);
