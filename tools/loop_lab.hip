@@ -161,7 +161,7 @@ __device__ __forceinline__ void bm_variant(uint32_t x, uint32_t y, float& n0, fl
     n1 = __builtin_amdgcn_cosf(w) * s;
 }
 
-template <int BMV, int PIPE>
+template <int BMV, int PIPE, int PRIO = 0>
 __global__ void __launch_bounds__(1024) lab2_kernel(float* out, uint64_t seed, int nblk, int iters)
 {
     const PhiloxKey key = philox_key(seed);
@@ -179,7 +179,13 @@ __global__ void __launch_bounds__(1024) lab2_kernel(float* out, uint64_t seed, i
                 c0 = w0; c1 = w1; c2 = w2; c3 = w3;
                 philox_block(key, pp, (uint32_t)(j + 1), w0, w1, w2, w3);
             } else {
+                if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+                if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
+                if (PRIO == 3) __builtin_amdgcn_s_setprio(3);
                 philox_block(key, pp, (uint32_t)j, c0, c1, c2, c3);
+                if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+                if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
+                if (PRIO == 3) __builtin_amdgcn_s_setprio(0);
             }
             float g[4];
             bm_variant<BMV>(c0, c1, g[0], g[1]);
@@ -188,6 +194,194 @@ __global__ void __launch_bounds__(1024) lab2_kernel(float* out, uint64_t seed, i
             for (int c = 0; c < 4; c++) { y = __builtin_fmaf(y, 0.99f, g[c]); S += y; }
         }
         sink += S + y + (PIPE ? (float)(w0 ^ w1 ^ w2 ^ w3) : 0.0f);
+    }
+    if (sink == 1.2345e-33f) out[t] = sink;
+}
+
+// ---- third family: s_setprio placement.  P_PHILOX / P_CVT / P_TRANS / P_STEP = priority (0..3) during that phase
+template <int P_PHILOX, int P_CVT, int P_TRANS, int P_STEP, int BMV = 0>
+__global__ void __launch_bounds__(1024) lab3_kernel(float* out, uint64_t seed, int nblk, int iters)
+{
+    const PhiloxKey key = philox_key(seed);
+    const int64_t T = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float sink = 0.0f;
+    constexpr float kInv = 2.3283064e-10f;
+    for (int it = 0; it < iters; it++) {
+        const PhiloxPath pp = philox_path(key, (uint64_t)(t + (int64_t)it * T));
+        float y = 0, S = 0;
+        for (int j = 0; j < nblk; j++) {
+            uint32_t c0, c1, c2, c3;
+            __builtin_amdgcn_s_setprio(P_PHILOX);
+            philox_block(key, pp, (uint32_t)j, c0, c1, c2, c3);
+            if (P_CVT != P_PHILOX) __builtin_amdgcn_s_setprio(P_CVT);
+            float u0 = __builtin_fmaf((float)c0, kInv, kInv), u1 = __builtin_fmaf((float)c2, kInv, kInv);
+            float a0, a1;
+            if (BMV == 0) { a0 = __builtin_fmaf((float)c1, kInv, kInv); a1 = __builtin_fmaf((float)c3, kInv, kInv); }
+            else { a0 = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, c1, 9)); a1 = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, c3, 9)); }
+            if (P_TRANS != P_CVT) __builtin_amdgcn_s_setprio(P_TRANS);
+            float s0, s1;
+            if (BMV == 2) { s0 = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u0)); s1 = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u1)); }
+            else { s0 = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u0) * -1.3862943611198906f); s1 = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u1) * -1.3862943611198906f); }
+            const float sn0 = __builtin_amdgcn_sinf(a0), cs0 = __builtin_amdgcn_cosf(a0);
+            const float sn1 = __builtin_amdgcn_sinf(a1), cs1 = __builtin_amdgcn_cosf(a1);
+            if (P_STEP != P_TRANS) __builtin_amdgcn_s_setprio(P_STEP);
+            const float g0 = sn0 * s0, g1 = cs0 * s0, g2 = sn1 * s1, g3 = cs1 * s1;
+            y = __builtin_fmaf(y, 0.99f, g0); S += y;
+            y = __builtin_fmaf(y, 0.99f, g1); S += y;
+            y = __builtin_fmaf(y, 0.99f, g2); S += y;
+            y = __builtin_fmaf(y, 0.99f, g3); S += y;
+        }
+        sink += S + y;
+    }
+    if (sink == 1.2345e-33f) out[t] = sink;
+}
+
+#define SETPRIO(n) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(n); __builtin_amdgcn_sched_barrier(0); } while (0)
+// ---- fourth family: refinements of "priority 1 from Box-Muller to the end of the block", BMV 2 arithmetic
+// EARLY: raise the priority before the last EARLY Philox rounds.  STAT: 1 = odd workgroups run at +1 priority throughout.
+// ILP: pairs in flight.
+__device__ __forceinline__ void philox_block_split(const PhiloxKey& k, const PhiloxPath& pp, uint32_t j, int early,
+                                                   uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3, int prio_hi)
+{
+    uint32_t hi0, lo0, hi1, lo1;
+    mulhilo(kM0, j, hi0, lo0);
+    uint32_t c2 = pp.A2 ^ hi0;
+    uint32_t c3 = lo0;
+    mulhilo(kM1, c2, hi1, lo1);
+    uint32_t c0 = hi1 ^ pp.Q;
+    uint32_t c1 = lo1;
+    c2 = pp.R ^ c3;
+    mulhilo(kM0, c0, hi0, lo0);
+    mulhilo(kM1, c2, hi1, lo1);
+    c0 = hi1 ^ c1 ^ k.k0[2];
+    c1 = lo1;
+    c2 = hi0 ^ pp.T;
+    c3 = lo0;
+#pragma unroll
+    for (int r = 3; r < 10; r++) {
+        if (r == 10 - early) { if (prio_hi == 2) SETPRIO(2); else SETPRIO(1); }
+        mulhilo(kM0, c0, hi0, lo0);
+        mulhilo(kM1, c2, hi1, lo1);
+        c0 = hi1 ^ c1 ^ k.k0[r];
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k.k1[r];
+        c3 = lo0;
+    }
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+
+template <int EARLY, int STAT, int ILP, int LOWER_AT = 0>
+__global__ void __launch_bounds__(1024) lab4_kernel(float* out, uint64_t seed, int nblk, int iters)
+{
+    const PhiloxKey key = philox_key(seed);
+    const int64_t T = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float sink = 0.0f;
+    constexpr float kInv = 2.3283064e-10f;
+    const int base = STAT ? (int)(blockIdx.x & 1) : 0;
+    for (int it = 0; it < iters; it++) {
+        PhiloxPath pp[ILP];
+        float y[ILP], S[ILP];
+        for (int q = 0; q < ILP; q++) { pp[q] = philox_path(key, (uint64_t)(t + (int64_t)(it * ILP + q) * T)); y[q] = 0; S[q] = 0; }
+        for (int j = 0; j < nblk; j++) {
+#pragma unroll
+            for (int q = 0; q < ILP; q++) {
+                uint32_t c0, c1, c2, c3;
+                if (base) SETPRIO(1); else SETPRIO(0);
+                uint32_t jj = (uint32_t)j;
+                asm volatile("" : "+s"(jj));                      // the block's Philox starts after the priority drop
+                philox_block_split(key, pp[q], jj, EARLY, c0, c1, c2, c3, base + 1);
+                asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));   // ... and is complete before the raise
+                if (EARLY == 0) { if (base) SETPRIO(2); else SETPRIO(1); }
+                asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));   // Box-Muller consumes them after the raise
+                const float u0 = __builtin_fmaf((float)c0, kInv, kInv), u1 = __builtin_fmaf((float)c2, kInv, kInv);
+                const float a0 = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, c1, 9)), a1 = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, c3, 9));
+                const float s0 = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u0)), s1 = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u1));
+                const float sn0 = __builtin_amdgcn_sinf(a0), cs0 = __builtin_amdgcn_cosf(a0);
+                const float sn1 = __builtin_amdgcn_sinf(a1), cs1 = __builtin_amdgcn_cosf(a1);
+                if (LOWER_AT == 1) { if (base) SETPRIO(1); else SETPRIO(0); }
+                const float g0 = sn0 * s0, g1 = cs0 * s0, g2 = sn1 * s1, g3 = cs1 * s1;
+                y[q] = __builtin_fmaf(y[q], 0.99f, g0); S[q] += y[q];
+                y[q] = __builtin_fmaf(y[q], 0.99f, g1); S[q] += y[q];
+                y[q] = __builtin_fmaf(y[q], 0.99f, g2); S[q] += y[q];
+                y[q] = __builtin_fmaf(y[q], 0.99f, g3); S[q] += y[q];
+            }
+        }
+        for (int q = 0; q < ILP; q++) sink += S[q] + y[q];
+    }
+    if (sink == 1.2345e-33f) out[t] = sink;
+}
+
+// ---- fifth family: priority also toggled inside the Philox rounds (mads high or xors high), BMV 2, trans high
+template <int MAD_PRIO, int XOR_PRIO, int BM_PRIO, int BMV = 2, int T3_PRIO = -1>
+__global__ void __launch_bounds__(1024) lab5_kernel(float* out, uint64_t seed, int nblk, int iters)
+{
+    const PhiloxKey k = philox_key(seed);
+    const int64_t T = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float sink = 0.0f;
+    constexpr float kInv = 2.3283064e-10f;
+    for (int it = 0; it < iters; it++) {
+        const PhiloxPath pp = philox_path(k, (uint64_t)(t + (int64_t)it * T));
+        float y = 0, S = 0;
+        for (int j = 0; j < nblk; j++) {
+            uint32_t jj = (uint32_t)j;
+            SETPRIO(XOR_PRIO);
+            asm volatile("" : "+s"(jj));
+            uint32_t hi0, lo0, hi1, lo1;
+            mulhilo(kM0, jj, hi0, lo0);
+            uint32_t c2 = pp.A2 ^ hi0;
+            uint32_t c3 = lo0;
+            mulhilo(kM1, c2, hi1, lo1);
+            uint32_t c0 = hi1 ^ pp.Q;
+            uint32_t c1 = lo1;
+            c2 = pp.R ^ c3;
+            mulhilo(kM0, c0, hi0, lo0);
+            mulhilo(kM1, c2, hi1, lo1);
+            c0 = hi1 ^ c1 ^ k.k0[2];
+            c1 = lo1;
+            c2 = hi0 ^ pp.T;
+            c3 = lo0;
+#pragma unroll
+            for (int r = 3; r < 10; r++) {
+                asm volatile("" : "+v"(c0), "+v"(c2));
+                if (MAD_PRIO != XOR_PRIO) SETPRIO(MAD_PRIO);
+                asm volatile("" : "+v"(c0), "+v"(c2));
+                mulhilo(kM0, c0, hi0, lo0);
+                mulhilo(kM1, c2, hi1, lo1);
+                asm volatile("" : "+v"(hi0), "+v"(hi1));
+                if (MAD_PRIO != XOR_PRIO) SETPRIO(XOR_PRIO);
+                asm volatile("" : "+v"(hi0), "+v"(hi1));
+                c0 = hi1 ^ c1 ^ k.k0[r];
+                c1 = lo1;
+                c2 = hi0 ^ c3 ^ k.k1[r];
+                c3 = lo0;
+            }
+            asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+            SETPRIO(BM_PRIO);
+            asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+            const float u0 = __builtin_fmaf((float)c0, kInv, kInv), u1 = __builtin_fmaf((float)c2, kInv, kInv);
+            float a0, a1;
+            if (BMV == 0) { a0 = __builtin_fmaf((float)c1, kInv, kInv); a1 = __builtin_fmaf((float)c3, kInv, kInv); }
+            else { a0 = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, c1, 9)); a1 = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, c3, 9)); }
+            float s0, s1;
+            if (BMV == 2) { s0 = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u0)); s1 = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u1)); }
+            else { s0 = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u0) * -1.3862943611198906f); s1 = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u1) * -1.3862943611198906f); }
+            float sn0 = __builtin_amdgcn_sinf(a0), cs0 = __builtin_amdgcn_cosf(a0);
+            float sn1 = __builtin_amdgcn_sinf(a1), cs1 = __builtin_amdgcn_cosf(a1);
+            if (T3_PRIO >= 0) {
+                asm volatile("" : "+v"(s0), "+v"(s1), "+v"(sn0), "+v"(cs0), "+v"(sn1), "+v"(cs1));
+                SETPRIO(T3_PRIO);
+                asm volatile("" : "+v"(s0), "+v"(s1), "+v"(sn0), "+v"(cs0), "+v"(sn1), "+v"(cs1));
+            }
+            const float g0 = sn0 * s0, g1 = cs0 * s0, g2 = sn1 * s1, g3 = cs1 * s1;
+            y = __builtin_fmaf(y, 0.99f, g0); S += y;
+            y = __builtin_fmaf(y, 0.99f, g1); S += y;
+            y = __builtin_fmaf(y, 0.99f, g2); S += y;
+            y = __builtin_fmaf(y, 0.99f, g3); S += y;
+        }
+        sink += S + y;
     }
     if (sink == 1.2345e-33f) out[t] = sink;
 }
@@ -232,6 +426,40 @@ int main(int argc, char** argv)
         {"L2 baseline         ", lab2_kernel<0, 0>, 1, philox + bm + step},
         {"L2 angle bits       ", lab2_kernel<1, 0>, 1, philox + bm + step},
         {"L2 angle+sqrt(-log) ", lab2_kernel<2, 0>, 1, philox + bm + step},
+        {"L2 prio philox hi   ", lab2_kernel<0, 0, 1>, 1, philox + bm + step},
+        {"L2 prio BM hi       ", lab2_kernel<0, 0, 2>, 1, philox + bm + step},
+        {"L2 prio philox 3    ", lab2_kernel<0, 0, 3>, 1, philox + bm + step},
+        {"L3 prio 0000        ", lab3_kernel<0, 0, 0, 0>, 1, philox + bm + step},
+        {"L3 prio 0111        ", lab3_kernel<0, 1, 1, 1>, 1, philox + bm + step},
+        {"L3 prio 0333        ", lab3_kernel<0, 3, 3, 3>, 1, philox + bm + step},
+        {"L3 prio 0123        ", lab3_kernel<0, 1, 2, 3>, 1, philox + bm + step},
+        {"L3 prio 0011        ", lab3_kernel<0, 0, 1, 1>, 1, philox + bm + step},
+        {"L3 prio 0010        ", lab3_kernel<0, 0, 1, 0>, 1, philox + bm + step},
+        {"L3 prio 0001        ", lab3_kernel<0, 0, 0, 1>, 1, philox + bm + step},
+        {"L3 prio 0100        ", lab3_kernel<0, 1, 0, 0>, 1, philox + bm + step},
+        {"L3 prio 0321        ", lab3_kernel<0, 3, 2, 1>, 1, philox + bm + step},
+        {"L3 prio 0111 bmv1   ", lab3_kernel<0, 1, 1, 1, 1>, 1, philox + bm + step},
+        {"L3 prio 0111 bmv2   ", lab3_kernel<0, 1, 1, 1, 2>, 1, philox + bm + step},
+        {"L4 early0           ", lab4_kernel<0, 0, 1>, 1, philox + bm + step},
+        {"L4 early1           ", lab4_kernel<1, 0, 1>, 1, philox + bm + step},
+        {"L4 early2           ", lab4_kernel<2, 0, 1>, 1, philox + bm + step},
+        {"L4 early4           ", lab4_kernel<4, 0, 1>, 1, philox + bm + step},
+        {"L4 early0 lower@T3  ", lab4_kernel<0, 0, 1, 1>, 1, philox + bm + step},
+        {"L4 early0 static    ", lab4_kernel<0, 1, 1>, 1, philox + bm + step},
+        {"L4 early0 ilp2      ", lab4_kernel<0, 0, 2>, 2, philox + bm + step},
+        {"L4 early2 ilp2      ", lab4_kernel<2, 0, 2>, 2, philox + bm + step},
+        {"L5 mad0 xor0 bm1    ", lab5_kernel<0, 0, 1>, 1, philox + bm + step},
+        {"L5 mad1 xor0 bm2    ", lab5_kernel<1, 0, 2>, 1, philox + bm + step},
+        {"L5 mad1 xor0 bm1    ", lab5_kernel<1, 0, 1>, 1, philox + bm + step},
+        {"L5 mad0 xor1 bm2    ", lab5_kernel<0, 1, 2>, 1, philox + bm + step},
+        {"L5 mad2 xor0 bm1    ", lab5_kernel<2, 0, 1>, 1, philox + bm + step},
+        {"L5 mad0 xor0 bm3    ", lab5_kernel<0, 0, 3>, 1, philox + bm + step},
+        {"L5 m1x0b1 bmv0      ", lab5_kernel<1, 0, 1, 0>, 1, philox + bm + step},
+        {"L5 m1x0b1 bmv1      ", lab5_kernel<1, 0, 1, 1>, 1, philox + bm + step},
+        {"L5 m1x0b1 bmv2 t3=0 ", lab5_kernel<1, 0, 1, 2, 0>, 1, philox + bm + step},
+        {"L5 m1x0b1 bmv0 t3=0 ", lab5_kernel<1, 0, 1, 0, 0>, 1, philox + bm + step},
+        {"L5 m2x0b1 bmv2 t3=0 ", lab5_kernel<2, 0, 1, 2, 0>, 1, philox + bm + step},
+        {"L5 m1x0b2 bmv2 t3=0 ", lab5_kernel<1, 0, 2, 2, 0>, 1, philox + bm + step},
         {"L2 pipelined        ", lab2_kernel<0, 1>, 1, philox + bm + step},
         {"L2 pipelined+tricks ", lab2_kernel<2, 1>, 1, philox + bm + step},
         {"philox only  asm rnd", lab_kernel<0, 1, false, false, true>, 1, philox + 4 * F},
