@@ -168,13 +168,12 @@ __device__ __forceinline__ void pin4(uint32_t& a, uint32_t& b, uint32_t& c, uint
     asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
-// Same words as philox_block(); leaves the wave at priority 1 (the caller's Box-Muller + steps run
-// there) and starts by dropping to 0.
+// Same words as philox_block().  Entered AND left at priority 1: the caller's Box-Muller + steps run
+// there, and so do the three multiplies of rounds 2-3 (measured: 272 -> 265 cycles per block against
+// dropping the priority at block entry); the xors run at priority 0.
 __device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const PhiloxPath& pp, uint32_t j,
                                                   uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
 {
-    HWK_SETPRIO(0);
-    asm volatile("" : "+s"(j));                     // this block's rounds start after the drop
     uint32_t hi0, lo0, hi1, lo1;
     mulhilo(kM0, j, hi0, lo0);                      // round 1 (scalar)
     uint32_t c2 = pp.A2 ^ hi0;
@@ -185,6 +184,9 @@ __device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const Phil
     c2 = pp.R ^ c3;
     mulhilo(kM0, c0, hi0, lo0);                     // round 3
     mulhilo(kM1, c2, hi1, lo1);
+    pin2(hi0, hi1);
+    HWK_SETPRIO(0);
+    pin2(hi0, hi1);
     c0 = hi1 ^ c1 ^ k.k0[2];
     c1 = lo1;
     c2 = hi0 ^ pp.T;
@@ -384,6 +386,7 @@ __device__ __forceinline__ void ou_walk(const PhiloxKey& key, const PhiloxPath (
                                         REAL e, REAL (&y)[ILP], REAL (&S)[ILP])
 {
     const int nblk = n_steps >> 2;
+    HWK_SETPRIO(1);
     for (int j = 0; j < nblk; j++) {
 #pragma unroll
         for (int q = 0; q < ILP; q++) {
@@ -535,6 +538,7 @@ zbc_reference_kernel(const ZbcRefArgs a, const float* __restrict__ drift, double
         if (!valid) p = 0;
         const PhiloxPath pp = philox_path(key, a.path_offset + (uint64_t)p);
         float r1 = a.r0, r2 = a.r0, I1 = 0.0f, I2 = 0.0f;           // common.cuh:318-319
+        HWK_SETPRIO(1);
         for (int i = 0; i < a.n_steps; i += 4) {                     // common.cuh:325-332
             float g[4];
             normal4_prio(key, pp, (uint32_t)(i >> 2), g);
@@ -613,6 +617,7 @@ zcb_curve_kernel(const ZcbArgs<REAL> a, double* __restrict__ partials)
         const PhiloxPath pp = philox_path(key, a.path_offset + (uint64_t)p);
         REAL y = 0, S = 0;
         int countdown = a.stride, m = 0;
+        HWK_SETPRIO(1);
         for (int i = 0; i < a.n_steps; i += 4) {
             float g[4];
             normal4_prio(key, pp, (uint32_t)(i >> 2), g);
