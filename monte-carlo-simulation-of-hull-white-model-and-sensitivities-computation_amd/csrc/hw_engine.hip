@@ -164,8 +164,9 @@ template <typename REAL>
 hwk::ZbcScen<REAL> make_scen(const Scenario& s, double K)
 {
     hwk::ZbcScen<REAL> z;
-    z.cz = (REAL)(s.k.dt * s.k.sig_st * kLog2e);
-    z.cw = (REAL)(s.B * s.k.sig_st * kLog2e);
+    // the kernels' y, S are the true ones divided by kBmScale: fold it into every factor that multiplies them
+    z.cz = (REAL)(s.k.dt * s.k.sig_st * kLog2e * hwk::kBmScale);
+    z.cw = (REAL)(s.B * s.k.sig_st * kLog2e * hwk::kBmScale);
     z.D0 = (REAL)std::exp(-s.cI_n);
     z.P0 = (REAL)(s.A * std::exp(-s.B * s.m_n));
     z.K = (REAL)K;
@@ -231,7 +232,7 @@ int launch_zbc_reference(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, con
     a.r0 = (float)c->p.r0;
     a.e = (float)s.k.e;
     a.dt = (float)s.k.dt;
-    a.sig_st = (float)s.k.sig_st;
+    a.sig_st = (float)(s.k.sig_st * hwk::kBmScale);       // normal4_prio yields G / kBmScale
     a.A = (float)s.A;
     a.B = (float)s.B;
     a.K = (float)r->K;
@@ -306,7 +307,7 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
     a.stride = stride;
     a.iters = g.iters;
     a.e = (REAL)k.e;
-    a.cz = (REAL)(k.dt * k.sig_st * kLog2e);
+    a.cz = (REAL)(k.dt * k.sig_st * kLog2e * hwk::kBmScale);
     const size_t lds = (size_t)(g.block / 64) * n_mat * sizeof(double);
     if (lds > 64 * 1024)
         return fail(HW_E_INVALID, "n_mat = %d needs %zu B of LDS per workgroup at block size %d (limit 65536): use a smaller block", n_mat, lds, g.block);
@@ -350,8 +351,8 @@ int launch_vega(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset,
     a.gB = (REAL)(p.sigma / (2.0 * p.a) * (-std::expm1(-2.0 * p.a * S1)) * s.B);
     a.Dn = (REAL)D[n_steps_S1];
     a.cD = (REAL)cD[n_steps_S1];
-    a.s_over_sigma = (REAL)(s.k.sig_st / p.sigma);
-    a.zs = (REAL)(s.k.dt * s.k.sig_st / p.sigma);
+    a.s_over_sigma = (REAL)(s.k.sig_st / p.sigma * hwk::kBmScale);
+    a.zs = (REAL)(s.k.dt * s.k.sig_st / p.sigma * hwk::kBmScale);
     unsigned* tk = c->single_launch ? c->d_ticket : nullptr;
     prof_mark(c, st, 0);
     if (ilp == 2)

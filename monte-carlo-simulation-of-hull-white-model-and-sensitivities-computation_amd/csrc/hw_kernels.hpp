@@ -212,13 +212,28 @@ __device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const Phil
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
 
-// The four normals of block j for the hot loops; exits at priority 1.
+// Box-Muller with the constant factor of the radius left out: sqrt(-2 ln u) = kBmScale * sqrt(-log2 u),
+// kBmScale = sqrt(2 ln 2).  The hot loops run their linear recursions on n / kBmScale and the host folds
+// kBmScale into the epilogue constants (exact algebra; saves the two scaling multiplies per block:
+// 270 -> 263 cycles).  v_sqrt_f32 takes the negated logarithm through its source modifier.
+constexpr double kBmScale = 1.1774100225154747;
+__device__ __forceinline__ void box_muller_unscaled(uint32_t x, uint32_t y, float& n0, float& n1)
+{
+    constexpr float kInv = 2.3283064e-10f;
+    const float u = __builtin_fmaf((float)x, kInv, kInv);
+    const float w = __builtin_fmaf((float)y, kInv, kInv);
+    const float s = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u));
+    n0 = __builtin_amdgcn_sinf(w) * s;
+    n1 = __builtin_amdgcn_cosf(w) * s;
+}
+
+// The four normals of block j, divided by kBmScale, for the hot loops; exits at priority 1.
 __device__ __forceinline__ void normal4_prio(const PhiloxKey& k, const PhiloxPath& pp, uint32_t j, float (&g)[4])
 {
     uint32_t w0, w1, w2, w3;
     philox_block_prio(k, pp, j, w0, w1, w2, w3);
-    box_muller(w0, w1, g[0], g[1]);
-    box_muller(w2, w3, g[2], g[3]);
+    box_muller_unscaled(w0, w1, g[0], g[1]);
+    box_muller_unscaled(w2, w3, g[2], g[3]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -377,7 +392,8 @@ __global__ void finalize_columns_kernel(const double* __restrict__ partials, int
 }
 
 // ------------------------------------------------------------------------------------------
-// The shared inner loop: y_{i+1} = e y_i + G_i,  S += y_{i+1}   (one fma + one add per step).
+// The shared inner loop: y_{i+1} = e y_i + G_i,  S += y_{i+1}   (one fma + one add per step), run on
+// G / kBmScale: the y and S it returns are the true ones divided by kBmScale (see box_muller_unscaled).
 // r_i = m_i +- s y_i and int r = cI +- dt s (S - y/2) are reconstructed in the epilogues from
 // host-computed m_n, cI_n (hw_model.hpp, mean_path).
 // ------------------------------------------------------------------------------------------
@@ -399,13 +415,12 @@ __device__ __forceinline__ void ou_walk(const PhiloxKey& key, const PhiloxPath (
             }
         }
     }
-    HWK_SETPRIO(0);
     const int rem = n_steps & 3;
     if (rem) {                                        // wave-uniform tail
 #pragma unroll
         for (int q = 0; q < ILP; q++) {
             float g[4];
-            normal4(key, pp[q], (uint32_t)nblk, g);
+            normal4_prio(key, pp[q], (uint32_t)nblk, g);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 if (c < rem) {
@@ -415,6 +430,7 @@ __device__ __forceinline__ void ou_walk(const PhiloxKey& key, const PhiloxPath (
             }
         }
     }
+    HWK_SETPRIO(0);
 }
 
 // ------------------------------------------------------------------------------------------

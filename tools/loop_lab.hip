@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(1024) lab5_kernel(float* out, uint64_t seed, i
 // 1 = only cvt+transcendentals at 1 (steps back at 0).
 #define PRIO_PIN2(n, a, b) asm volatile("s_setprio " #n : "+v"(a), "+v"(b))
 #define PRIO_PIN4(n, a, b, c, d) asm volatile("s_setprio " #n : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-template <int FIRST, int TAIL>
+template <int FIRST, int TAIL, int BMV = 0>
 __global__ void __launch_bounds__(1024) lab6_kernel(float* out, uint64_t seed, int nblk, int iters)
 {
     const PhiloxKey k = philox_key(seed);
@@ -433,8 +433,11 @@ __global__ void __launch_bounds__(1024) lab6_kernel(float* out, uint64_t seed, i
             }
             PRIO_PIN4(1, c0, c1, c2, c3);
             const float u0 = __builtin_fmaf((float)c0, kInv, kInv), u1 = __builtin_fmaf((float)c2, kInv, kInv);
-            const float a0 = __builtin_fmaf((float)c1, kInv, kInv), a1 = __builtin_fmaf((float)c3, kInv, kInv);
-            float s0 = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u0) * -1.3862943611198906f), s1 = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u1) * -1.3862943611198906f);
+            float a0, a1, s0, s1;
+            if (BMV == 0) { a0 = __builtin_fmaf((float)c1, kInv, kInv); a1 = __builtin_fmaf((float)c3, kInv, kInv); }
+            else { a0 = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, c1, 9)); a1 = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, c3, 9)); }
+            if (BMV == 2) { s0 = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u0)); s1 = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u1)); }
+            else { s0 = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u0) * -1.3862943611198906f); s1 = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u1) * -1.3862943611198906f); }
             float sn0 = __builtin_amdgcn_sinf(a0), cs0 = __builtin_amdgcn_cosf(a0);
             float sn1 = __builtin_amdgcn_sinf(a1), cs1 = __builtin_amdgcn_cosf(a1);
             if (TAIL == 1) asm volatile("s_setprio 0" : "+v"(s0), "+v"(s1), "+v"(sn0), "+v"(cs0), "+v"(sn1), "+v"(cs1));
@@ -525,6 +528,8 @@ int main(int argc, char** argv)
         {"L5 m1x0b2 bmv2 t3=0 ", lab5_kernel<1, 0, 2, 2, 0>, 1, philox + bm + step},
         {"L6 fused first0 t0  ", lab6_kernel<0, 0>, 1, philox + bm + step},
         {"L6 fused first1 t0  ", lab6_kernel<1, 0>, 1, philox + bm + step},
+        {"L6 first1 t0 bmv1   ", lab6_kernel<1, 0, 1>, 1, philox + bm + step},
+        {"L6 first1 t0 bmv2   ", lab6_kernel<1, 0, 2>, 1, philox + bm + step},
         {"L6 fused first0 t1  ", lab6_kernel<0, 1>, 1, philox + bm + step},
         {"L6 fused first1 t1  ", lab6_kernel<1, 1>, 1, philox + bm + step},
         {"L2 pipelined        ", lab2_kernel<0, 1>, 1, philox + bm + step},
