@@ -124,8 +124,8 @@ Geometry geometry(const hw_ctx* c, int64_t n_units, int ilp)
 int finish_columns(hw_ctx* c, hipStream_t st, int rows, int ncol, double* d_out)
 {
     if (c->single_launch) return HW_OK;
-    hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(ncol), dim3(256), 0, st, (const double*)c->d_partials, rows, ncol,
-                       (const double*)nullptr, -1.0, d_out);
+    hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(ncol), dim3(256), 0, st, (const double*)c->d_partials, rows,
+                       1, rows, (const double*)nullptr, -1.0, d_out);
     HIP_TRY(hipGetLastError());
     return HW_OK;
 }
@@ -316,7 +316,7 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
     prof_mark(c, st, 1);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(n_mat), dim3(256), 0, st, (const double*)c->d_partials,
-                       g.grid, n_mat, (const double*)c->d_scale, 2.0 * (double)n_pairs, d_P_sum);
+                       g.grid, n_mat, 1, (const double*)c->d_scale, 2.0 * (double)n_pairs, d_P_sum);
     HIP_TRY(hipGetLastError());
     return HW_OK;
 }

@@ -314,7 +314,7 @@ __device__ __forceinline__ void grid_sum_finish(double (&v)[N], double* smem /*[
         if (lane < N) {
             double t = 0.0;
             for (int w = 0; w < nwaves; w++) t += smem[w * N + lane];
-            double* dst = partials + (size_t)blockIdx.x * N + lane;
+            double* dst = partials + (size_t)lane * gridDim.x + blockIdx.x;      // column-major: [N][grid]
             if (ticket == nullptr) *dst = t;
             else __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(t),
                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -347,7 +347,7 @@ __device__ __forceinline__ void grid_sum_finish(double (&v)[N], double* smem /*[
     for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            const unsigned long long bits = __hip_atomic_load(reinterpret_cast<unsigned long long*>(partials + (size_t)b * N + k),
+            const unsigned long long bits = __hip_atomic_load(reinterpret_cast<unsigned long long*>(partials + (size_t)k * gridDim.x + b),
                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             acc[k] += __longlong_as_double((long long)bits);
         }
@@ -366,17 +366,19 @@ __device__ __forceinline__ void grid_sum_finish(double (&v)[N], double* smem /*[
     if (threadIdx.x < 9) __hip_atomic_store(ticket + threadIdx.x * kTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Second (tiny) launch: out[k] = scale[k] * sum_b partials[b*ncol + k], fixed order.
+// Second (tiny) launch: out[k] = scale[k] * sum_b partials[b*row_stride + k*col_stride], fixed order.
+// The moment kernels store column-major ([N][grid]: row_stride 1, col_stride grid -> coalesced reads here),
+// the curve kernel row-major ([grid][n_mat]: its 101-wide rows are written coalesced instead).
 // grid = ncol workgroups of 256 threads.  fix0: if >= 0, out[0] is overwritten with that value
 // (P_sum[0] = 2 N of market_data.cuh:76-78, done without the reference's write race).
-__global__ void finalize_columns_kernel(const double* __restrict__ partials, int nrows, int ncol,
+__global__ void finalize_columns_kernel(const double* __restrict__ partials, int nrows, int row_stride, int col_stride,
                                         const double* __restrict__ scale, double fix0,
                                         double* __restrict__ out)
 {
     __shared__ double smem[256];
     const int k = blockIdx.x;
     double t = 0.0;
-    for (int b = threadIdx.x; b < nrows; b += blockDim.x) t += partials[(size_t)b * ncol + k];
+    for (int b = threadIdx.x; b < nrows; b += blockDim.x) t += partials[(size_t)b * row_stride + (size_t)k * col_stride];
     smem[threadIdx.x] = t;
     __syncthreads();
     for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
