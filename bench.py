@@ -30,8 +30,8 @@ sys.path.insert(0, ROOT)
 # (instruction counts from the gfx950 disassembly, issue cycles per wave64 instruction per SIMD
 #  measured by tools/valu_rates.hip on MI355X: full rate 2, half rate 4, quarter rate 8).
 VALU_MODEL = {
-    "superposed": {"full": 53, "half": 21, "quarter": 8},   # 34 xor,4 fmamk,6 mul,4 fmac,4 add,1 mov | 17 mad_u64,4 cvt | 2 log,2 sqrt,2 sin,2 cos
-    "reference": {"full": 81, "half": 21, "quarter": 8},    # + per-step: sG mul, 2 add, 2 fma, 2 add, 2 mul/fma pairs on two legs
+    "superposed": {"full": 51, "half": 21, "quarter": 8},   # 34 xor,4 fmamk,4 mul,4 fmac,4 add,1 mov | 17 mad_u64,4 cvt | 2 log,2 sqrt,2 sin,2 cos
+    "reference": {"full": 79, "half": 21, "quarter": 8},    # + per-step: sG mul, 2 add, 2 fma, 2 add, 2 mul/fma pairs on two legs
 }
 # Issue costs measured on MI355X at 8 waves/SIMD (tools/valu_rates.hip, tools/valu_patterns.hip; profiles/):
 # "full-rate" ops sustain one per 2.3 cycles (two waves issue side by side; one wave alone: 4.7),
