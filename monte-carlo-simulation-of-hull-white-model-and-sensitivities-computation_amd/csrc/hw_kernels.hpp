@@ -761,8 +761,8 @@ __global__ void sample_paths_kernel(float* __restrict__ out, const float* __rest
 }
 
 // Device RNG probe: normals (hoisted Philox) of one subsequence, plus the raw words of every
-// block computed twice -- raw[8j..8j+3] by the hoisted form the kernels use, raw[8j+4..8j+7] by
-// the plain ten-round form -- so a test can pin both against the oracle / rocRAND.
+// block computed twice -- raw[8j..8j+3] by the hoisted, prioritised form the kernels use, raw[8j+4..8j+7]
+// by the plain ten-round form -- so a test can pin both against the oracle / rocRAND.
 __global__ void debug_normals_kernel(float* __restrict__ out, uint32_t* __restrict__ raw, uint64_t seed,
                                      uint64_t subseq, int n_blocks)
 {
@@ -770,11 +770,13 @@ __global__ void debug_normals_kernel(float* __restrict__ out, uint32_t* __restri
     if (j >= n_blocks) return;
     const PhiloxKey key = philox_key(seed);
     const PhiloxPath pp = philox_path(key, subseq);
+    // exactly what the hot loops consume: the prioritised block and the unscaled Box-Muller, rescaled here
     float g[4];
-    normal4(key, pp, (uint32_t)j, g);
-    for (int c = 0; c < 4; c++) out[4 * j + c] = g[c];
+    normal4_prio(key, pp, (uint32_t)j, g);
+    for (int c = 0; c < 4; c++) out[4 * j + c] = g[c] * (float)kBmScale;
     uint32_t o[4], h0, h1, h2, h3;
-    philox_block(key, pp, (uint32_t)j, h0, h1, h2, h3);
+    philox_block_prio(key, pp, (uint32_t)j, h0, h1, h2, h3);
+    HWK_SETPRIO(0);
     philox_block_plain(seed, subseq, (uint64_t)j, o);
     raw[8 * j + 0] = h0; raw[8 * j + 1] = h1; raw[8 * j + 2] = h2; raw[8 * j + 3] = h3;
     for (int c = 0; c < 4; c++) raw[8 * j + 4 + c] = o[c];
