@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--stepper", default="superposed", choices=["superposed", "reference"])
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--profile", default="head", choices=["head", "readme"])
+    ap.add_argument("--block", type=int, default=0, help="threads per workgroup (0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--spinup-ms", type=float, default=400.0,
@@ -119,6 +120,8 @@ def main():
     e = hwmc.HullWhiteEngine(p, device=local_rank)
     P, f = hwmc.analytic_curve(p)                      # synthetic market input (exact curve)
     e.load_market_data(P, f)
+    if a.block:
+        e.set_launch(block_size=a.block)
     stepper = hwmc.HW_STEPPER_SUPERPOSED if a.stepper == "superposed" else hwmc.HW_STEPPER_REFERENCE
     K, W = a.steps, a.warmup
     out = torch.zeros((K + W, 5), dtype=torch.float64, device=dev)
@@ -214,7 +217,7 @@ def main():
         # around the whole timed region additionally contains the 4.7 us column pass and the launch gaps.
         kavg = float(np.mean(kernel_ms))
         region_per_step = region_ms / K
-        geo_blocks = min((n_pairs + 255) // 256, 1 << 20)   # one 256-thread workgroup per 256 pairs (csrc/hw_engine.hip geometry())
+        geo_blocks = min((n_pairs + (a.block or 512) - 1) // (a.block or 512), 1 << 20)   # one 256-thread workgroup per 256 pairs (csrc/hw_engine.hip geometry())
         algo_bytes = geo_blocks * 5 * 8 + 5 * 8            # partial rows written + the 5 sums (stateless Philox: no state traffic)
         achieved = algo_bytes / (kavg * 1e-3) / 1e9
         traffic, traffic_src = None, None

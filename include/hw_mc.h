@@ -115,7 +115,8 @@ int  hw_get_params(hw_ctx* ctx, hw_params* out);
  * (the data/P.bin, data/f.bin layout). */
 int  hw_set_market(hw_ctx* ctx, const float* P, const float* f, int32_t n_mat);
 
-/* Launch-geometry knobs: threads per block (64..1024, multiple of 64; 0 keeps the current),
+/* Launch-geometry knobs: threads per block (64..1024, multiple of 64; 0 keeps the current, -1 returns to the
+ * automatic choice: 512 when the batch gives every CU >= 4 such workgroups, else 256),
  * grid cap in workgroups per CU (0 = as many as 32 waves per CU hold), drift-table staging for
  * the REFERENCE stepper (0 scalar loads, 1 LDS), pairs in flight per thread (1 or 2). */
 int  hw_set_launch(hw_ctx* ctx, int32_t block_size, int32_t max_blocks_per_cu, int32_t table_in_lds,

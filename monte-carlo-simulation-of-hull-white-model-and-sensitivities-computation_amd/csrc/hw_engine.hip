@@ -63,7 +63,7 @@ struct hw_ctx {
     unsigned* d_ticket = nullptr;     // grid_sum_finish ticket counter (self re-arming)
     unsigned long long* d_clk = nullptr;  // clock probe of the last superposed ZBC launch (4 words)
     // launch knobs
-    int block_size = 256;
+    int block_size = 0;               // 0 = automatic (see geometry())
     int max_blocks_per_cu = 0;        // in units of block_size-thread workgroups; 0 = default
     int table_in_lds = 0;
     int ilp = 1;
@@ -109,7 +109,11 @@ inline void prof_mark(hw_ctx* c, hipStream_t st, int which)
 Geometry geometry(const hw_ctx* c, int64_t n_units, int ilp, bool wide_rows = false)
 {
     Geometry g{};
+    // Workgroup size: 512 threads once that still gives every CU >= 4 workgroups (half as many rows for the
+    // column pass: +1 % per pricing call at 2^20 pairs; 1024 is as good for the ZBC kernel but 10 % slower for
+    // the Vega and multi-scenario kernels), else 256 so that small batches spread over the chip.
     g.block = c->block_size;
+    if (g.block == 0) g.block = (n_units >= (int64_t)2048 * c->prop.multiProcessorCount * ilp) ? 512 : 256;
     const int64_t per_block = (int64_t)g.block * ilp;
     int64_t want = (n_units + per_block - 1) / per_block;
     if (want < 1) want = 1;
@@ -526,7 +530,9 @@ int hw_set_launch(hw_ctx* c, int32_t block_size, int32_t max_blocks_per_cu, int3
                   int32_t pairs_in_flight)
 {
     if (!c) return fail(HW_E_INVALID, "null context");
-    if (block_size) {
+    if (block_size == -1) {
+        c->block_size = 0;                                        // back to automatic
+    } else if (block_size) {
         if (block_size < 64 || block_size > 1024 || block_size % 64) return fail(HW_E_INVALID, "block_size must be a multiple of 64 in [64,1024]");
         c->block_size = block_size;
     }
@@ -772,9 +778,9 @@ int hw_get_kernel_info(hw_ctx* c, const char* kernel, hw_kernel_info* out)
     out->lds_bytes = (int32_t)attr.sharedSizeBytes;
     out->scratch_bytes = (int32_t)attr.localSizeBytes;
     out->max_threads_per_block = attr.maxThreadsPerBlock;
-    out->block_size = c->block_size;
+    out->block_size = c->block_size ? c->block_size : 256;
     int nb = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, c->block_size, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, out->block_size, 0));
     out->blocks_per_cu = nb;
     return HW_OK;
 }

@@ -57,7 +57,7 @@ static void block_size_sweep(app::Fleet& fleet, int64_t n, uint64_t seed)
         if (avg < best_ms) { best_ms = avg; best = bs; }
     }
     printf("\nBest configuration: %d threads/workgroup (%.3f ms)\n", best, best_ms);
-    HW_CHECK(hw_set_launch(fleet.ctx[0], 256, 0, 0, 1));
+    HW_CHECK(hw_set_launch(fleet.ctx[0], -1, 0, 0, 1));
 }
 
 int main(int argc, char** argv)

@@ -134,7 +134,7 @@ def test_zbc_lds_table_variant_and_launch_knobs(setup, hwmc_mod):
             np.testing.assert_allclose(e.simulate_zcb(700, 5), o.zcb_curve(700, 5), rtol=REL_F32)
             assert e.simulate_sensitivity(n, 9) == pytest.approx(o.vega_pathwise(P, f, n, 9), rel=REL_F32)
     finally:
-        e.set_launch(256, 0, 0, 1)
+        e.set_launch(-1, 0, 0, 1)
 
 
 def test_zbc_edge_cases_and_sharding(setup, hwmc_mod):
