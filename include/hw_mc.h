@@ -131,6 +131,13 @@ int  hw_zbc_moments(hw_ctx* ctx, const hw_zbc_request* req, double out[5], float
  * `stream` (a hipStream_t; NULL = the context's stream).  No host synchronisation. */
 int  hw_zbc_moments_async(hw_ctx* ctx, const hw_zbc_request* req, double* d_out, void* stream);
 
+/* n_runs independent pricings in ONE launch: run k uses seed + k*seed_stride on the same pairs
+ * [path_offset, path_offset + n_pairs).  Replaces the 20 malloc / init_rng / launch / 5x D2H cycles of
+ * run_zbc_statistical_validation (src/2_option_pricing.cu:225-302); out[n_runs*5], run-major.  Each run's
+ * sums are bit-identical to a separate hw_zbc_moments call with that seed.  SUPERPOSED stepper only. */
+int  hw_zbc_moments_runs(hw_ctx* ctx, const hw_zbc_request* req, int32_t n_runs, uint64_t seed_stride,
+                         double* out, float* kernel_ms);
+
 /* Up to 3 volatility scenarios priced from ONE pass over the same random numbers (common
  * random numbers by construction).  Replaces the three kernel launches + state restores of
  * run_finite_difference (3_sens:400-446): scenario k uses sigma[k] and drift_mode[k].

@@ -60,6 +60,7 @@ SIGNATURES = {
     "hw_set_launch": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "hw_zbc_moments": (C.c_int, [_CTX, C.POINTER(HwZbcRequest), _DP, _FP]),
     "hw_zbc_moments_async": (C.c_int, [_CTX, C.POINTER(HwZbcRequest), C.c_void_p, C.c_void_p]),
+    "hw_zbc_moments_runs": (C.c_int, [_CTX, C.POINTER(HwZbcRequest), C.c_int32, C.c_uint64, _DP, _FP]),
     "hw_zbc_scenarios": (C.c_int, [_CTX, C.POINTER(HwZbcRequest), C.c_int32, _DP,
                                    C.POINTER(C.c_int32), _DP, _FP]),
     "hw_zcb_curve": (C.c_int, [_CTX, C.c_int64, C.c_uint64, C.c_uint64, C.c_double, _DP, _FP]),

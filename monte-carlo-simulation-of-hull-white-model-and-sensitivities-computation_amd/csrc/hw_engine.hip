@@ -130,11 +130,11 @@ Geometry geometry(const hw_ctx* c, int64_t n_units, int ilp, bool wide_rows = fa
 }
 
 // second launch of the default two-launch finish (no-op when the kernel finished in-launch)
-int finish_columns(hw_ctx* c, hipStream_t st, int rows, int ncol, double* d_out)
+int finish_columns(hw_ctx* c, hipStream_t st, int rows, int ncol, double* d_out, int n_groups = 1)
 {
-    if (c->single_launch) return HW_OK;
-    hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(ncol), dim3(256), 0, st, (const double*)c->d_partials, rows,
-                       1, rows, (const double*)nullptr, -1.0, d_out);
+    if (c->single_launch && n_groups == 1) return HW_OK;
+    hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(ncol * n_groups), dim3(256), 0, st, (const double*)c->d_partials, rows,
+                       1, rows * n_groups, (const double*)nullptr, -1.0, d_out, ncol);
     HIP_TRY(hipGetLastError());
     return HW_OK;
 }
@@ -197,11 +197,13 @@ int check_request(hw_ctx* c, const hw_zbc_request* r, int* n_steps_S1)
 
 template <typename REAL, int NSCEN>
 int launch_zbc_superposed(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, const Scenario* sc,
-                          double* d_out, hipStream_t st)
+                          double* d_out, hipStream_t st, int n_runs = 1, uint64_t seed_stride = 0)
 {
     const int ilp = c->ilp;
     const Geometry g = geometry(c, r->n_pairs, ilp);
-    int rc = ensure_partials(c, (size_t)g.grid * 5 * NSCEN);
+    if ((int64_t)g.grid * n_runs > ((int64_t)1 << 22)) return fail(HW_E_INVALID, "n_runs x workgroups per run exceeds 2^22");
+    const int total_grid = g.grid * n_runs;
+    int rc = ensure_partials(c, (size_t)total_grid * 5 * NSCEN);
     if (rc) return rc;
     hwk::ZbcArgs<REAL, NSCEN> a{};
     a.n_pairs = r->n_pairs;
@@ -212,15 +214,17 @@ int launch_zbc_superposed(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, co
     a.e = (REAL)sc[0].k.e;
     for (int k = 0; k < NSCEN; k++) a.sc[k] = make_scen<REAL>(sc[k], r->K);
     a.clk = c->prof_cap > 0 ? c->d_clk : nullptr;
-    unsigned* tk = c->single_launch ? c->d_ticket : nullptr;
+    a.blocks_per_run = (uint32_t)g.grid;
+    a.seed_stride = seed_stride;
+    unsigned* tk = (c->single_launch && n_runs == 1) ? c->d_ticket : nullptr;
     prof_mark(c, st, 0);
     if (ilp == 2)
-        hipLaunchKernelGGL((hwk::zbc_superposed_kernel<REAL, NSCEN, 2>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials, tk, d_out);
+        hipLaunchKernelGGL((hwk::zbc_superposed_kernel<REAL, NSCEN, 2>), dim3(total_grid), dim3(g.block), 0, st, a, c->d_partials, tk, d_out);
     else
-        hipLaunchKernelGGL((hwk::zbc_superposed_kernel<REAL, NSCEN, 1>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials, tk, d_out);
+        hipLaunchKernelGGL((hwk::zbc_superposed_kernel<REAL, NSCEN, 1>), dim3(total_grid), dim3(g.block), 0, st, a, c->d_partials, tk, d_out);
     prof_mark(c, st, 1);
     HIP_TRY(hipGetLastError());
-    return finish_columns(c, st, g.grid, 5 * NSCEN, d_out);
+    return finish_columns(c, st, g.grid, 5 * NSCEN, d_out, n_runs);
 }
 
 int launch_zbc_reference(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, const Scenario& s,
@@ -325,7 +329,7 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
     prof_mark(c, st, 1);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(n_mat), dim3(256), 0, st, (const double*)c->d_partials,
-                       g.grid, n_mat, 1, (const double*)c->d_scale, 2.0 * (double)n_pairs, d_P_sum);
+                       g.grid, n_mat, 1, (const double*)c->d_scale, 2.0 * (double)n_pairs, d_P_sum, n_mat);
     HIP_TRY(hipGetLastError());
     return HW_OK;
 }
@@ -568,6 +572,24 @@ int hw_zbc_scenarios(hw_ctx* c, const hw_zbc_request* r, int32_t n_scen, const d
     if (n_scen < 1 || n_scen > hwk::kMaxScen) return fail(HW_E_INVALID, "n_scen must be 1..%d", hwk::kMaxScen);
     return timed_sync(c, 5 * n_scen, out, kernel_ms, [&](double* d_out, hipStream_t st) {
         return zbc_enqueue(c, r, n_scen, sigma, drift_mode, d_out, st);
+    });
+}
+
+int hw_zbc_moments_runs(hw_ctx* c, const hw_zbc_request* r, int32_t n_runs, uint64_t seed_stride, double* out,
+                        float* kernel_ms)
+{
+    if (!c || !r || !out) return fail(HW_E_INVALID, "null argument");
+    if (n_runs < 1 || 5 * n_runs > kOutCap) return fail(HW_E_INVALID, "n_runs must be 1..%d", kOutCap / 5);
+    if (r->stepper != HW_STEPPER_SUPERPOSED) return fail(HW_E_INVALID, "batched runs use the SUPERPOSED stepper");
+    int n_steps_S1 = 0;
+    int rc = check_request(c, r, &n_steps_S1);
+    if (rc) return rc;
+    Scenario sc;
+    rc = build_scenario(c, r->sigma, r->drift_mode, n_steps_S1, r->S1, r->S2, &sc);
+    if (rc) return rc;
+    return timed_sync(c, 5 * n_runs, out, kernel_ms, [&](double* d_out, hipStream_t st) {
+        return c->p.precision == HW_F64 ? launch_zbc_superposed<double, 1>(c, r, n_steps_S1, &sc, d_out, st, n_runs, seed_stride)
+                                        : launch_zbc_superposed<float, 1>(c, r, n_steps_S1, &sc, d_out, st, n_runs, seed_stride);
     });
 }
 

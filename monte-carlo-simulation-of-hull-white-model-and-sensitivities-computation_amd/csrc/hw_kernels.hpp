@@ -366,19 +366,21 @@ __device__ __forceinline__ void grid_sum_finish(double (&v)[N], double* smem /*[
     if (threadIdx.x < 9) __hip_atomic_store(ticket + threadIdx.x * kTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Second (tiny) launch: out[k] = scale[k] * sum_b partials[b*row_stride + k*col_stride], fixed order.
+// Second (tiny) launch: out[g*ncol + k] = scale[k] * sum_{b < nrows} partials[(g*nrows + b)*row_stride + k*col_stride],
+// fixed order; grid = ncol * n_groups workgroups (n_groups > 1: several runs finished by one launch).
 // The moment kernels store column-major ([N][grid]: row_stride 1, col_stride grid -> coalesced reads here),
 // the curve kernel row-major ([grid][n_mat]: its 101-wide rows are written coalesced instead).
 // grid = ncol workgroups of 256 threads.  fix0: if >= 0, out[0] is overwritten with that value
 // (P_sum[0] = 2 N of market_data.cuh:76-78, done without the reference's write race).
 __global__ void finalize_columns_kernel(const double* __restrict__ partials, int nrows, int row_stride, int col_stride,
                                         const double* __restrict__ scale, double fix0,
-                                        double* __restrict__ out)
+                                        double* __restrict__ out, int ncol)
 {
     __shared__ double smem[256];
-    const int k = blockIdx.x;
+    const int k = blockIdx.x % ncol, group = blockIdx.x / ncol;
+    const size_t row0 = (size_t)group * nrows;
     double t = 0.0;
-    for (int b = threadIdx.x; b < nrows; b += blockDim.x) t += partials[(size_t)b * row_stride + (size_t)k * col_stride];
+    for (int b = threadIdx.x; b < nrows; b += blockDim.x) t += partials[(row0 + b) * row_stride + (size_t)k * col_stride];
     smem[threadIdx.x] = t;
     __syncthreads();
     for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
@@ -389,7 +391,7 @@ __global__ void finalize_columns_kernel(const double* __restrict__ partials, int
         double r = smem[0];
         if (scale) r *= scale[k];
         if (k == 0 && fix0 >= 0.0) r = fix0;
-        out[k] = r;
+        out[(size_t)group * ncol + k] = r;
     }
 }
 
@@ -455,6 +457,10 @@ struct ZbcArgs {
     REAL e;
     ZbcScen<REAL> sc[NSCEN];
     unsigned long long* clk;   // optional: workgroup 0 stores {s_memtime, s_memrealtime} at entry and exit
+    // several independent runs in one launch (the 20-run validation, 2_option:210-468): workgroup b belongs
+    // to run b / blocks_per_run and uses seed + run * seed_stride.  One run: blocks_per_run = gridDim.x.
+    uint32_t blocks_per_run;
+    uint64_t seed_stride;
 };
 
 template <typename REAL, int NSCEN, int ILP>
@@ -469,9 +475,11 @@ zbc_superposed_kernel(const ZbcArgs<REAL, NSCEN> a, double* __restrict__ partial
         a.clk[0] = __builtin_amdgcn_s_memtime();
         a.clk[1] = __builtin_amdgcn_s_memrealtime();
     }
-    const PhiloxKey key = philox_key(a.seed);
-    const int64_t T = (int64_t)gridDim.x * blockDim.x;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t run = blockIdx.x / a.blocks_per_run;
+    const uint32_t block_in_run = blockIdx.x - run * a.blocks_per_run;
+    const PhiloxKey key = philox_key(a.seed + (uint64_t)run * a.seed_stride);
+    const int64_t T = (int64_t)a.blocks_per_run * blockDim.x;
+    const int64_t t = (int64_t)block_in_run * blockDim.x + threadIdx.x;
 
     double acc[5 * NSCEN];
 #pragma unroll

@@ -179,6 +179,17 @@ class HullWhiteEngine:
         L.check(self.lib.hw_zbc_moments_async(self._ctx, C.byref(r), C.c_void_p(d_out_ptr),
                                               C.c_void_p(stream or 0)))
 
+    def simulate_ZBC_runs(self, n_pairs, seed, n_runs=20, seed_stride=12345, path_offset=0, S1=5.0, S2=10.0,
+                          K=None, return_ms=False):
+        """n_runs independent pricings (seed + k*seed_stride; 2_option:229) in ONE launch -> float64[n_runs, 5]."""
+        r = self._request(n_pairs, seed, path_offset, S1, S2, K, 0.0, L.HW_DRIFT_BASE, L.HW_STEPPER_SUPERPOSED)
+        out = np.zeros(5 * n_runs, np.float64)
+        ms = C.c_float(0)
+        L.check(self.lib.hw_zbc_moments_runs(self._ctx, C.byref(r), int(n_runs), int(seed_stride), _dp(out),
+                                             C.byref(ms)))
+        out = out.reshape(n_runs, 5)
+        return (out, ms.value) if return_ms else out
+
     def simulate_ZBC_scenarios(self, n_pairs, seed, sigmas, drift_modes, path_offset=0, S1=5.0,
                                S2=10.0, K=None, return_ms=False):
         """len(sigmas) <= 3 scenarios from one pass over the same draws -> float64[n, 5]."""

@@ -85,9 +85,18 @@ static void validation(app::Fleet& fleet, const app::Options& opt, int64_t n, ui
     const int runs = 20;
     std::vector<double> adj(runs), raw(runs), beta(runs), rho(runs);
     printf("Running %d independent Monte Carlo simulations...\n", runs);
+    // one device: all 20 runs in ONE launch (per-run moment slots); several devices: 20 sharded calls
+    std::vector<double> all(5 * runs, 0.0);
+    const bool batched = fleet.ctx.size() == 1 && opt.stepper == HW_STEPPER_SUPERPOSED;
+    if (batched) {
+        const hw_zbc_request r = option_request(opt, n, base_seed);
+        float ms = 0.0f;
+        HW_CHECK(hw_zbc_moments_runs(fleet.ctx[0], &r, runs, 12345ull, all.data(), &ms));
+        printf("  (one launch of %d x %lld pairs: %.2f ms, %.2f M paths/sec)\n", runs, (long long)n, ms, (2.0 * n * runs / ms) / 1000.0);
+    }
     for (int k = 0; k < runs; k++) {
-        double sums[5];
-        fleet.zbc(option_request(opt, n, base_seed + (uint64_t)k * 12345ull), sums, nullptr);   // 2_option:229
+        double* sums = &all[5 * k];
+        if (!batched) fleet.zbc(option_request(opt, n, base_seed + (uint64_t)k * 12345ull), sums, nullptr);   // 2_option:229
         const app::CvResult c = app::cv_price(sums, 2 * n, P0S2);
         adj[k] = c.price; raw[k] = c.mean_X; beta[k] = c.beta; rho[k] = c.rho;
         if ((k + 1) % 5 == 0) printf("  Completed %d/%d runs...\n", k + 1, runs);

@@ -158,6 +158,27 @@ def test_zbc_edge_cases_and_sharding(setup, hwmc_mod):
     assert not np.array_equal(whole, e.simulate_ZBC_control_variate(10000, 10))
 
 
+def test_zbc_batched_runs_equal_separate_launches(setup, hwmc_mod):
+    """The 20-run validation in one launch (hw_zbc_moments_runs): every run bit-identical to its own launch."""
+    for prec in ("f32", "f64"):
+        e, o, P, f = setup("head", prec)
+        for n in (1000, 1 << 14):
+            runs = e.simulate_ZBC_runs(n, 555, n_runs=20, seed_stride=12345, path_offset=77)
+            assert runs.shape == (20, 5)
+            for k in (0, 1, 7, 19):
+                single = e.simulate_ZBC_control_variate(n, 555 + 12345 * k, path_offset=77)
+                assert np.array_equal(runs[k], single)
+        np.testing.assert_allclose(runs[3], o.zbc_moments(P, f, 1 << 14, 555 + 3 * 12345, path_offset=77),
+                                   rtol=REL_F32 if prec == "f32" else REL_F64)
+    e, _, P, f = setup("readme")
+    big, ms = e.simulate_ZBC_runs(1 << 20, 1234, return_ms=True)                   # 20 x 2^21 paths, one launch
+    prices = [hwmc_mod.cv_price(s, 2 << 20, float(P[-1]))["price"] for s in big]
+    st = hwmc_mod.run_statistics(prices)
+    assert abs(st["mean"] - 0.03544557) < 3 * st["se"] + 2e-6 and st["cv_percent"] < 0.15   # README: CV 0.0496 %
+    with pytest.raises(hwmc_mod.HwError):
+        e.simulate_ZBC_runs(16, 1, n_runs=0)
+
+
 def test_zbc_other_option_and_grid(setup, hwmc_mod):
     """S1/S2/K other than the hard-coded 5/10/e^-0.1, a 4000-step grid (2000 executed steps) and a
     step count that is not a multiple of 4 (tail of the 4-normals-per-Philox-block loop)."""
