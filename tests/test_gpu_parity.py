@@ -348,15 +348,18 @@ def test_full_size_properties_2pow20(setup, hwmc_mod):
     np.testing.assert_allclose(whole, eighths, rtol=1e-13)
     ref = e.simulate_ZBC_control_variate(n, 1234, stepper=hwmc_mod.HW_STEPPER_REFERENCE)
     np.testing.assert_allclose(whole, ref, rtol=REL_F32)                            # two steppers agree
-    # an oracle sample of the same stream: pairs [0, 2^15) are a shard of the full run
-    m = 1 << 15
-    np.testing.assert_allclose(e.simulate_ZBC_control_variate(m, 1234), o.zbc_moments(P, f, m, 1234), rtol=REL_F32)
+    # the oracle on the SAME 2^20 pairs (about a second of OpenMP work on the GPU box's host cores)
+    np.testing.assert_allclose(whole, o.zbc_moments(P, f, n, 1234), rtol=REL_F32)
+    ow = hwmc_mod.cv_price(o.zbc_moments(P, f, n, 1234), 2 * n, float(P[-1]))
+    gw = hwmc_mod.cv_price(whole, 2 * n, float(P[-1]))
+    assert gw["price"] == pytest.approx(ow["price"], rel=REL_F32) and gw["beta"] == pytest.approx(ow["beta"], rel=REL_F32)
     r = hwmc_mod.cv_price(whole, 2 * n, float(P[-1]))
     assert abs(r["price"] - 0.03544557) < 4 * r["ci95_halfwidth"] / 1.96            # exact Jamshidian
     assert r["beta"] == pytest.approx(0.166309, abs=1e-3)
     assert r["rho"] == pytest.approx(0.6738, abs=2e-3)
     vega = e.simulate_sensitivity(n, 99) / n
     assert vega == pytest.approx(0.230244, abs=1.5e-3)                              # analytic Vega
+    assert vega == pytest.approx(o.vega_pathwise(P, f, n, 99) / n, rel=REL_F32)     # oracle, same 2^20 paths
     fd = e.run_finite_difference(n, 99)
     assert fd["vega_fd"] == pytest.approx(0.230244, abs=2e-3)
     assert abs(fd["vega_fd"] - vega) / vega < 0.02                                  # README.md:49-50: 0.18 %
