@@ -70,7 +70,7 @@ def cpu_baseline(P, f, profile, grid_steps, seconds):
     t0 = time.perf_counter()
     o.zbc_moments(P, f, 1 << 13, 1)                      # calibration
     rate = (1 << 13) / max(time.perf_counter() - t0, 1e-6)
-    n = int(min(max(rate * seconds, 1 << 13), 1 << 23))
+    n = int(min(max(rate * seconds, 1 << 13), 1 << 25))
     t0 = time.perf_counter()
     o.zbc_moments(P, f, n, 2)
     dt = time.perf_counter() - t0
@@ -199,6 +199,22 @@ def main():
     torch.cuda.synchronize()
     kernel_ms = e.profile_read(K)
     clock_mhz = e.profile_clock_mhz() if a.stepper == "superposed" else None
+    # For the record, the OTHER stepper on the same workload (untimed w.r.t. the headline; N = 1 only): the
+    # reference's per-step arithmetic verbatim vs the superposed recursion, so both numbers sit in one line.
+    alt = None
+    if world == 1:
+        other = hwmc.HW_STEPPER_REFERENCE if a.stepper == "superposed" else hwmc.HW_STEPPER_SUPERPOSED
+        if not (other == hwmc.HW_STEPPER_REFERENCE and a.precision != "f32"):
+            for _ in range(3):
+                e.enqueue_ZBC(scratch.data_ptr(), n_pairs, 5, path_offset=offset, stepper=other, stream=stream)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for i in range(K):
+                e.enqueue_ZBC(scratch.data_ptr(), n_pairs, 1234 + 12345 * i, path_offset=offset, stepper=other, stream=stream)
+            torch.cuda.synchronize()
+            alt_ms = (time.perf_counter() - ta) * 1e3 / K
+            alt = {"stepper": "reference" if other == hwmc.HW_STEPPER_REFERENCE else "superposed",
+                   "ms_per_step": alt_ms, "value": (2 * n_pairs / alt_ms) / 1000.0, "unit": "M paths/s"}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -262,6 +278,7 @@ def main():
                      "measured_issue_cycles_per_op": MEASURED_ISSUE, "issue_cycles_per_4_steps_at_measured_rates": cyc_meas,
                      "achieved_cycles_per_wave_per_4_steps": achieved_cyc, "frac_of_measured_rate_ceiling": cyc_meas / achieved_cyc},
             "kernel_Mpaths_per_sec": (2 * n_pairs / kavg) / 1000.0,
+            "other_stepper": alt,
             "device": info["name"],
         }
         if rehearsal:
