@@ -556,6 +556,7 @@ zbc_reference_kernel(const ZbcRefArgs a, const float* __restrict__ drift, double
     const int64_t T = (int64_t)gridDim.x * blockDim.x;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     constexpr float kLog2e = 1.4426950408889634f;
+    const float half_dt = 0.5f * a.dt;                  // exact (power-of-two scaling)
 
     double acc[5] = {0, 0, 0, 0, 0};
     for (int it = 0; it < a.iters; it++) {
@@ -574,10 +575,10 @@ zbc_reference_kernel(const ZbcRefArgs a, const float* __restrict__ drift, double
                     const float d = tab[i + c];
                     const float sG = a.sig_st * g[c];
                     const float r1n = __builtin_fmaf(r1, a.e, d + sG);   // common.cuh:241
-                    I1 += 0.5f * (r1 + r1n) * a.dt;                       // common.cuh:242
+                    I1 += (r1 + r1n) * half_dt;                           // common.cuh:242; 0.5f*x*dt == x*(0.5f*dt) bit for bit
                     r1 = r1n;
                     const float r2n = __builtin_fmaf(r2, a.e, d - sG);
-                    I2 += 0.5f * (r2 + r2n) * a.dt;
+                    I2 += (r2 + r2n) * half_dt;
                     r2 = r2n;
                 }
             }
