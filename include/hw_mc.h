@@ -186,6 +186,20 @@ int  hw_profile_clock(hw_ctx* ctx, double* shader_mhz);
 int  hw_get_kernel_info(hw_ctx* ctx, const char* kernel /* "zbc" | "zbc_ref" | "zcb" | "vega" */,
                         hw_kernel_info* out);
 
+/* ---- several GPUs in one process ---------------------------------------------------------------
+ * (not in the reference, which is single-GPU).  A communicator spans contexts created on DIFFERENT
+ * devices with identical parameters and market curves.  Each call shards the paths by global id
+ * (context g gets a contiguous block), launches every device asynchronously and sums the results with
+ * ONE grouped ncclAllReduce (RCCL over xGMI; librccl.so.1 is loaded at hw_comm_create, the library
+ * itself does not link it).  wall_ms: host wall time from the first launch to the reduced result. */
+typedef struct hw_comm hw_comm;
+int  hw_comm_create(int32_t n, hw_ctx* const* ctxs, hw_comm** out);
+void hw_comm_destroy(hw_comm* comm);
+int  hw_comm_zbc_moments(hw_comm* comm, const hw_zbc_request* req, double out[5], float* wall_ms);
+int  hw_comm_zcb_curve(hw_comm* comm, int64_t n_pairs, uint64_t seed, double sigma, double* P_sum, float* wall_ms);
+int  hw_comm_vega_pathwise(hw_comm* comm, int64_t n_paths, uint64_t seed, double S1, double S2, double K,
+                           int32_t antithetic, double out[1], float* wall_ms);
+
 /* ---- host-side pieces of the path (no GPU work) ----------------------------------------- */
 /* The tables the launch for (sigma, drift_mode) uses: compute_drift_tables / shifted table.
  * drift, sigma_drift: n_steps doubles each (either may be NULL). */

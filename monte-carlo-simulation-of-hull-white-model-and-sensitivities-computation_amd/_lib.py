@@ -77,6 +77,12 @@ SIGNATURES = {
     "hw_profile_read": (C.c_int, [_CTX, _FP, C.c_int32, C.POINTER(C.c_int32)]),
     "hw_profile_clock": (C.c_int, [_CTX, _DP]),
     "hw_get_kernel_info": (C.c_int, [_CTX, C.c_char_p, C.POINTER(HwKernelInfo)]),
+    "hw_comm_create": (C.c_int, [C.c_int32, C.POINTER(_CTX), C.POINTER(C.c_void_p)]),
+    "hw_comm_destroy": (None, [C.c_void_p]),
+    "hw_comm_zbc_moments": (C.c_int, [C.c_void_p, C.POINTER(HwZbcRequest), _DP, C.POINTER(C.c_float)]),
+    "hw_comm_zcb_curve": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_double, _DP, C.POINTER(C.c_float)]),
+    "hw_comm_vega_pathwise": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_double, C.c_double,
+                                        C.c_int32, _DP, C.POINTER(C.c_float)]),
     "hw_drift_tables": (C.c_int, [_CTX, C.c_double, C.c_int32, _DP, _DP]),
     "hw_average_and_forward": (C.c_int, [C.POINTER(HwParams), _DP, C.c_int64, _FP, _FP]),
     "hw_recover_theta": (C.c_int, [C.POINTER(HwParams), _FP, _FP, _FP, _FP]),

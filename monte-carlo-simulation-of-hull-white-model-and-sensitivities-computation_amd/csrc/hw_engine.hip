@@ -6,11 +6,14 @@
 // There is NO CPU fallback in this library: every compute entry point launches HIP kernels
 // and fails with HW_E_HIP if the runtime or the GPU is unavailable.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types and prototypes only: librccl.so.1 is dlopen'ed by hw_comm_create
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -902,6 +905,146 @@ int hw_analytic_curve(const hw_params* p, float* P, float* f)
         f[j] = (float)fv;
     }
     return HW_OK;
+}
+
+
+}  // extern "C"
+
+// ---- multi-GPU in one process: shard over several contexts, one RCCL all-reduce over xGMI ----------
+struct hw_comm {
+    std::vector<hw_ctx*> ctx;
+    std::vector<ncclComm_t> comm;
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+#define NCCL_TRY(cm, expr)                                                                              \
+    do {                                                                                                \
+        ncclResult_t r_ = (expr);                                                                       \
+        if (r_ != ncclSuccess) return fail(HW_E_HIP, "RCCL error [%s]: %s", #expr, (cm)->GetErrorString(r_)); \
+    } while (0)
+
+// shard [0, n) in contiguous blocks: rank g gets {offset, count}
+static void comm_shard(int64_t n, int g, int G, int64_t* off, int64_t* cnt)
+{
+    const int64_t base = n / G, rem = n % G;
+    *off = g * base + std::min<int64_t>(g, rem);
+    *cnt = base + (g < rem ? 1 : 0);
+}
+
+// enqueue(g, offset, count, d_out, stream) on every device, then ONE grouped all-reduce of `count_out` doubles
+template <typename F>
+static int comm_run(hw_comm* cm, int64_t n_units, int count_out, double* out, float* wall_ms, F enqueue)
+{
+    if (count_out > kOutCap) return fail(HW_E_INVALID, "too many outputs");
+    const int G = (int)cm->ctx.size();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int g = 0; g < G; g++) {
+        hw_ctx* c = cm->ctx[g];
+        HIP_TRY(hipSetDevice(c->device));
+        int64_t off, cnt;
+        comm_shard(n_units, g, G, &off, &cnt);
+        int rc = enqueue(g, off, cnt, c->d_out, c->stream);          // asynchronous: all devices run concurrently
+        if (rc) return rc;
+    }
+    NCCL_TRY(cm, cm->GroupStart());
+    for (int g = 0; g < G; g++) {
+        hw_ctx* c = cm->ctx[g];
+        NCCL_TRY(cm, cm->AllReduce(c->d_out, c->d_out, (size_t)count_out, ncclDouble, ncclSum, cm->comm[g], c->stream));
+    }
+    NCCL_TRY(cm, cm->GroupEnd());
+    HIP_TRY(hipSetDevice(cm->ctx[0]->device));
+    HIP_TRY(hipMemcpyAsync(out, cm->ctx[0]->d_out, count_out * sizeof(double), hipMemcpyDeviceToHost, cm->ctx[0]->stream));
+    for (int g = 0; g < G; g++) {
+        HIP_TRY(hipSetDevice(cm->ctx[g]->device));
+        HIP_TRY(hipStreamSynchronize(cm->ctx[g]->stream));
+    }
+    if (wall_ms) *wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return HW_OK;
+}
+
+extern "C" {
+
+int hw_comm_create(int32_t n, hw_ctx* const* ctxs, hw_comm** out)
+{
+    if (!out || !ctxs || n < 1 || n > 64) return fail(HW_E_INVALID, "bad argument");
+    *out = nullptr;
+    hw_comm* cm = new (std::nothrow) hw_comm();
+    if (!cm) return fail(HW_E_NOMEM, "out of host memory");
+    cm->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!cm->lib) cm->lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!cm->lib) { delete cm; return fail(HW_E_HIP, "cannot load RCCL (librccl.so.1): %s", dlerror()); }
+    cm->CommInitAll = (decltype(cm->CommInitAll))dlsym(cm->lib, "ncclCommInitAll");
+    cm->AllReduce = (decltype(cm->AllReduce))dlsym(cm->lib, "ncclAllReduce");
+    cm->GroupStart = (decltype(cm->GroupStart))dlsym(cm->lib, "ncclGroupStart");
+    cm->GroupEnd = (decltype(cm->GroupEnd))dlsym(cm->lib, "ncclGroupEnd");
+    cm->CommDestroy = (decltype(cm->CommDestroy))dlsym(cm->lib, "ncclCommDestroy");
+    cm->GetErrorString = (decltype(cm->GetErrorString))dlsym(cm->lib, "ncclGetErrorString");
+    if (!cm->CommInitAll || !cm->AllReduce || !cm->GroupStart || !cm->GroupEnd || !cm->CommDestroy || !cm->GetErrorString) {
+        delete cm;
+        return fail(HW_E_HIP, "RCCL library lacks a required symbol");
+    }
+    std::vector<int> devs;
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i]) { delete cm; return fail(HW_E_INVALID, "null context %d", i); }
+        for (int d : devs) if (d == ctxs[i]->device) { delete cm; return fail(HW_E_INVALID, "device %d used twice", d); }
+        cm->ctx.push_back(ctxs[i]);
+        devs.push_back(ctxs[i]->device);
+    }
+    cm->comm.resize(n);
+    ncclResult_t r = cm->CommInitAll(cm->comm.data(), n, devs.data());
+    if (r != ncclSuccess) {
+        const char* msg = cm->GetErrorString(r);
+        delete cm;
+        return fail(HW_E_HIP, "ncclCommInitAll: %s", msg);
+    }
+    *out = cm;
+    return HW_OK;
+}
+
+void hw_comm_destroy(hw_comm* cm)
+{
+    if (!cm) return;
+    for (size_t i = 0; i < cm->comm.size(); i++) {
+        (void)hipSetDevice(cm->ctx[i]->device);
+        (void)cm->CommDestroy(cm->comm[i]);
+    }
+    delete cm;   // the library handle stays loaded for the life of the process
+}
+
+int hw_comm_zbc_moments(hw_comm* cm, const hw_zbc_request* r, double out[5], float* wall_ms)
+{
+    if (!cm || !r || !out) return fail(HW_E_INVALID, "null argument");
+    return comm_run(cm, r->n_pairs, 5, out, wall_ms, [&](int g, int64_t off, int64_t cnt, double* d_out, hipStream_t st) {
+        hw_zbc_request q = *r;
+        q.n_pairs = cnt;
+        q.path_offset = r->path_offset + (uint64_t)off;
+        return zbc_enqueue(cm->ctx[g], &q, 1, nullptr, nullptr, d_out, st);
+    });
+}
+
+int hw_comm_zcb_curve(hw_comm* cm, int64_t n_pairs, uint64_t seed, double sigma, double* P_sum, float* wall_ms)
+{
+    if (!cm || !P_sum) return fail(HW_E_INVALID, "null argument");
+    const int n_mat = cm->ctx[0]->p.n_mat;
+    int rc = comm_run(cm, n_pairs, n_mat, P_sum, wall_ms, [&](int g, int64_t off, int64_t cnt, double* d_out, hipStream_t st) {
+        return zcb_enqueue(cm->ctx[g], cnt, seed, (uint64_t)off, sigma, d_out, st);
+    });
+    return rc;                                                        // column 0: every shard wrote 2*its count
+}
+
+int hw_comm_vega_pathwise(hw_comm* cm, int64_t n_paths, uint64_t seed, double S1, double S2, double K,
+                          int32_t antithetic, double out[1], float* wall_ms)
+{
+    if (!cm || !out) return fail(HW_E_INVALID, "null argument");
+    return comm_run(cm, n_paths, 1, out, wall_ms, [&](int g, int64_t off, int64_t cnt, double* d_out, hipStream_t st) {
+        return vega_enqueue(cm->ctx[g], cnt, seed, (uint64_t)off, S1, S2, K, antithetic, d_out, st);
+    });
 }
 
 }  // extern "C"

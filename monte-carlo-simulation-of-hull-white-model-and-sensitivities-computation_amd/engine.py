@@ -308,3 +308,49 @@ class HullWhiteEngine:
         L.check(self.lib.hw_debug_raw(self._ctx, int(seed), int(subseq), int(n_blocks),
                                       out.ctypes.data_as(C.POINTER(C.c_uint32))))
         return out.reshape(n_blocks, 4)
+
+
+class HullWhiteFleet:
+    """Several engines (one per device) in ONE process behind an RCCL communicator: every call shards the
+    paths by global id, launches all devices asynchronously and sums with one grouped ncclAllReduce
+    (hw_comm_*, include/hw_mc.h).  bench.py uses one process per GPU with torch.distributed instead
+    (parallel.py); this class is what the q1/q2/q3 executables use for --gpus N."""
+
+    def __init__(self, engines):
+        self.lib = L.load()
+        self.engines = list(engines)
+        arr = (C.c_void_p * len(self.engines))(*[e._ctx for e in self.engines])
+        self._comm = C.c_void_p()
+        L.check(self.lib.hw_comm_create(len(self.engines), arr, C.byref(self._comm)))
+
+    def close(self):
+        if self._comm:
+            self.lib.hw_comm_destroy(self._comm)
+            self._comm = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def simulate_ZBC_control_variate(self, n_pairs, seed, path_offset=0, S1=5.0, S2=10.0, K=None, sigma=0.0,
+                                     drift_mode=L.HW_DRIFT_BASE, stepper=L.HW_STEPPER_SUPERPOSED,
+                                     return_ms=False):
+        r = self.engines[0]._request(n_pairs, seed, path_offset, S1, S2, K, sigma, drift_mode, stepper)
+        out = np.zeros(5, np.float64)
+        ms = C.c_float(0)
+        L.check(self.lib.hw_comm_zbc_moments(self._comm, C.byref(r), _dp(out), C.byref(ms)))
+        return (out, ms.value) if return_ms else out
+
+    def simulate_zcb(self, n_pairs, seed, sigma=0.0):
+        out = np.zeros(self.engines[0].params.n_mat, np.float64)
+        L.check(self.lib.hw_comm_zcb_curve(self._comm, int(n_pairs), int(seed), float(sigma), _dp(out), None))
+        return out
+
+    def simulate_sensitivity(self, n_paths, seed, S1=5.0, S2=10.0, K=None, antithetic=False):
+        out = np.zeros(1, np.float64)
+        L.check(self.lib.hw_comm_vega_pathwise(self._comm, int(n_paths), int(seed), float(S1), float(S2),
+                                               float(K_DEFAULT if K is None else K), int(bool(antithetic)),
+                                               _dp(out), None))
+        return float(out[0])

@@ -21,7 +21,7 @@ int main(int argc, char** argv)
     printf("  theta profile = %s (theta(t>=5) = %.3f + %.3f t)\n\n", opt.profile.c_str(), p.th_a2, p.th_b2);
 
     app::Fleet fleet;
-    fleet.create(p, opt.gpus, opt.device);
+    fleet.create(p, opt.gpus, opt.device, opt.reduce);
     const uint64_t seed = opt.have_seed ? opt.seed : (uint64_t)time(nullptr);      // 1_bond:53
     printf("RNG: Philox4x32-10, seed %llu, subsequence = path id (no state to initialise)\n", (unsigned long long)seed);
 

@@ -152,7 +152,7 @@ int main(int argc, char** argv)
     const int64_t n = opt.n();
     app::ensure_dirs();
     app::Fleet fleet;
-    fleet.create(p, opt.gpus, opt.gpus == 1 && opt.device == 0 ? -1 : opt.device);   // select_gpu()
+    fleet.create(p, opt.gpus, opt.gpus == 1 && opt.device == 0 ? -1 : opt.device, opt.reduce);   // select_gpu()
     printf("Q2: Theta Recovery & Option Pricing\n");
     std::vector<float> P, f;
     app::load_market(opt, p, &P, &f);

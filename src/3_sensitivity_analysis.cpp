@@ -68,7 +68,7 @@ int main(int argc, char** argv)
     const double K = (double)expf(-0.1f);
     app::ensure_dirs();
     app::Fleet fleet;
-    fleet.create(p, opt.gpus, opt.gpus == 1 && opt.device == 0 ? -1 : opt.device);
+    fleet.create(p, opt.gpus, opt.gpus == 1 && opt.device == 0 ? -1 : opt.device, opt.reduce);
     printf("---Question 3: Sensitivity Analysis---\n\n");
     std::vector<float> P, f;
     app::load_market(opt, p, &P, &f);

@@ -44,6 +44,7 @@ struct Options {
     int stepper = HW_STEPPER_SUPERPOSED;
     std::string market = "mc";
     int gpus = 1, device = 0;
+    int reduce = -1;   // cross-device sum: -1 automatic (RCCL when --gpus > 1), 0 host threads, 1 RCCL all-reduce
     int answer = -1;   // -1 ask on stdin, 0 no, 1 yes
     int64_t n() const { return (int64_t)1 << paths_log2; }
 };
@@ -73,6 +74,7 @@ inline Options parse(int argc, char** argv)
         else if (a == "--market") o.market = val();
         else if (a == "--gpus") o.gpus = atoi(val());
         else if (a == "--device") o.device = atoi(val());
+        else if (a == "--reduce") o.reduce = !strcmp(val(), "rccl") ? 1 : 0;
         else if (a == "--yes") o.answer = 1;
         else if (a == "--no") o.answer = 0;
         else { fprintf(stderr, "unknown flag %s (see src/hw_app.hpp)\n", a.c_str()); exit(2); }
@@ -199,8 +201,9 @@ inline FILE* summary_section(const char* path, const char* title)
 // ---- engines: one context per GPU; paths sharded by global id, sums added on the host --------
 struct Fleet {
     std::vector<hw_ctx*> ctx;
+    hw_comm* comm = nullptr;   // non-null: shard + ONE grouped ncclAllReduce inside the library (hw_comm_*)
     hw_params p{};
-    void create(const hw_params& params, int gpus, int first_device)
+    void create(const hw_params& params, int gpus, int first_device, int reduce = -1)
     {
         p = params;
         for (int g = 0; g < gpus; g++) {
@@ -212,9 +215,13 @@ struct Fleet {
         HW_CHECK(hw_get_device_info(ctx[0], &di));
         printf("Using GPU %d: %s, %d CUs, %.2f GB%s\n\n", di.device, di.name, di.compute_units, di.hbm_bytes / 1e9,
                gpus > 1 ? " (+ more devices)" : "");
+        if (reduce == 1 || (reduce < 0 && gpus > 1)) {
+            HW_CHECK(hw_comm_create((int32_t)ctx.size(), ctx.data(), &comm));
+            printf("Cross-device sums: RCCL all-reduce over %d device%s\n\n", gpus, gpus > 1 ? "s" : "");
+        }
     }
     void set_market(const float* P, const float* f) { for (hw_ctx* c : ctx) HW_CHECK(hw_set_market(c, P, f, p.n_mat)); }
-    void destroy() { for (hw_ctx* c : ctx) hw_destroy(c); ctx.clear(); }
+    void destroy() { hw_comm_destroy(comm); comm = nullptr; for (hw_ctx* c : ctx) hw_destroy(c); ctx.clear(); }
     // shard [0, n) over the devices; returns {offset, count} of device g
     void shard(int64_t n, int g, int64_t* off, int64_t* cnt) const
     {
@@ -239,6 +246,7 @@ struct Fleet {
     // ZBC moments over n pairs (all devices), kernel time = slowest device
     void zbc(hw_zbc_request r, double out[5], float* ms)
     {
+        if (comm) { HW_CHECK(hw_comm_zbc_moments(comm, &r, out, ms)); return; }
         const size_t G = ctx.size();
         std::vector<double> part(5 * G, 0.0);
         std::vector<float> t(G, 0.0f);
@@ -256,6 +264,7 @@ struct Fleet {
     }
     void zcb(int64_t n, uint64_t seed, double sigma, std::vector<double>* P_sum, float* ms)
     {
+        if (comm) { P_sum->assign(p.n_mat, 0.0); HW_CHECK(hw_comm_zcb_curve(comm, n, seed, sigma, P_sum->data(), ms)); return; }
         const size_t G = ctx.size();
         std::vector<double> part((size_t)p.n_mat * G, 0.0);
         std::vector<float> t(G, 0.0f);
@@ -270,6 +279,7 @@ struct Fleet {
     }
     double vega(int64_t n, uint64_t seed, double S1, double S2, double K, float* ms)
     {
+        if (comm) { double t = 0.0; HW_CHECK(hw_comm_vega_pathwise(comm, n, seed, S1, S2, K, 0, &t, ms)); return t; }
         const size_t G = ctx.size();
         std::vector<double> part(G, 0.0);
         std::vector<float> t(G, 0.0f);

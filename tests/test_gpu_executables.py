@@ -81,3 +81,22 @@ def test_exact_market_and_reference_stepper_flags(built, tmp_path):
     r = _run("q2", tmp_path, "--paths-log2", "16", "--seed", "3", "--market", "exact", "--stepper", "reference",
              "--precision", "f32", "--no")
     assert "Market curve: exact" in r.stdout and "ZBC (control variate adjusted):" in r.stdout
+
+
+def test_rccl_reduce_flag_gives_the_same_files(built, tmp_path):
+    """--reduce rccl routes the cross-device sums through hw_comm_* (a one-rank RCCL communicator on this
+    box); curve and price must equal the default host-side path digit for digit."""
+    a, b = tmp_path / "host", tmp_path / "rccl"
+    a.mkdir(); b.mkdir()
+    common = ("--paths-log2", "16", "--seed", "11", "--theta-profile", "readme")
+    _run("q1", a, *common)
+    r = _run("q1", b, *common, "--reduce", "rccl")
+    assert "Cross-device sums: RCCL all-reduce over 1 device" in r.stdout
+    assert np.array_equal(np.fromfile(a / "data" / "P.bin", np.float32), np.fromfile(b / "data" / "P.bin", np.float32))
+    _run("q2", a, *common, "--no")
+    _run("q2", b, *common, "--reduce", "rccl", "--no")
+    ja, jb = (json.load(open(d / "data" / "q2b_results.json")) for d in (a, b))
+    assert ja["results"] == jb["results"]
+    _run("q3", a, *common, "--no")
+    r3 = _run("q3", b, *common, "--reduce", "rccl", "--no")
+    assert "ERROR" not in r3.stdout

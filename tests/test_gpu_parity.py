@@ -368,3 +368,25 @@ def test_full_size_properties_2pow20(setup, hwmc_mod):
     Pmc, fmc = e.compute_average_and_forward(c, 2 * n)
     assert float(np.max(np.abs(Pmc - P))) < 4e-4                                    # ~4 SE at 2^21 paths
     assert ms > 0
+
+
+# ---- in-process communicator (hw_comm_*: shard + one grouped ncclAllReduce) ---------------------
+def test_comm_one_device_equals_single_context(setup, hwmc_mod):
+    """Only one GPU is visible to this suite, so the communicator has one rank: the RCCL all-reduce is
+    then an identity on the staged sums and every result must equal the single-context call BIT FOR BIT
+    (the >1 rank arithmetic -- contiguous shards by global path id, sums of doubles -- is what
+    test_zbc_edge_cases_and_sharding / test_full_size_properties_2pow20 check through path_offset)."""
+    e, o, P, f = setup("readme")
+    n = 50_001
+    with hwmc_mod.HullWhiteFleet([e]) as fleet:
+        a, ms = fleet.simulate_ZBC_control_variate(n, 77, return_ms=True)
+        assert np.array_equal(a, e.simulate_ZBC_control_variate(n, 77)) and ms > 0
+        np.testing.assert_allclose(a, o.zbc_moments(P, f, n, 77), rtol=REL_F32)
+        assert np.array_equal(fleet.simulate_ZBC_control_variate(n, 77, path_offset=1000),
+                              e.simulate_ZBC_control_variate(n, 77, path_offset=1000))
+        c = fleet.simulate_zcb(n, 5)
+        assert np.array_equal(c, e.simulate_zcb(n, 5)) and c[0] == 2.0 * n
+        assert fleet.simulate_sensitivity(n, 9) == e.simulate_sensitivity(n, 9)
+        assert np.array_equal(fleet.simulate_ZBC_control_variate(0, 1), np.zeros(5))
+    with pytest.raises(hwmc_mod.HwError):
+        hwmc_mod.HullWhiteFleet([e, e])                                             # one device twice
