@@ -13,6 +13,12 @@ which the 95 % CI width of the metric is computed.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+Pipelining: the K steps are independent pricing batches, so each GPU alternates them over S contexts (S HIP
+streams, --streams, default 2): the ~15 us a 2^20-pair launch loses to launch latency and fill/drain
+(tools/size_scan.py) is filled by the next batch's waves.  Every batch is still one full launch; the sums are
+bit-identical to the single-stream run (tools/overlap_probe.py) and the JSON line also carries the
+single-stream figure ("serial").
+
 N > 1: one process per GPU; rank g prices global pairs [g*n, (g+1)*n) of an N*n-pair run (weak
 scaling), and each step's five moment sums are all-reduced over RCCL (asynchronously, so the
 all-reduce of step i overlaps the kernel of step i+1).  Rank 0 prints ONE JSON line.
@@ -27,11 +33,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # VALU issue model of the path kernel's inner loop, per Philox block = 4 time steps of one pair
-# (instruction counts from the gfx950 disassembly, issue cycles per wave64 instruction per SIMD
+# (instruction counts from the gfx950 disassembly -- tools/loop_census.py --, issue cycles per wave64 instruction per SIMD
 #  measured by tools/valu_rates.hip on MI355X: full rate 2, half rate 4, quarter rate 8).
 VALU_MODEL = {
-    "superposed": {"full": 51, "half": 21, "quarter": 8},   # 34 xor,4 fmamk,4 mul,4 fmac,4 add,1 mov | 17 mad_u64,4 cvt | 2 log,2 sqrt,2 sin,2 cos
-    "reference": {"full": 79, "half": 21, "quarter": 8},    # + per-step: sG mul, 2 add, 2 fma, 2 add, 2 mul/fma pairs on two legs
+    "superposed": {"full": 36, "half": 21, "quarter": 8},   # 15 bitop3,4 xor,4 fmamk,4 mul,4 fmac,4 add,1 mov | 17 mad_u64,4 cvt | 2 log,2 sqrt,2 sin,2 cos
+    "reference": {"full": 64, "half": 21, "quarter": 8},    # + per-step: sG mul, 2 add, 2 fma, 2 add, 2 mul/fma pairs on two legs
 }
 # Issue costs measured on MI355X at 8 waves/SIMD (tools/valu_rates.hip, tools/valu_patterns.hip; profiles/):
 # "full-rate" ops sustain one per 2.3 cycles (two waves issue side by side; one wave alone: 4.7),
@@ -52,6 +58,8 @@ def parse():
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--profile", default="head", choices=["head", "readme"])
     ap.add_argument("--block", type=int, default=0, help="threads per workgroup (0 = engine default)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="contexts (HIP streams) per GPU the independent steps alternate over; 1 = strictly serial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--spinup-ms", type=float, default=400.0,
@@ -87,6 +95,8 @@ def cpu_baseline(P, f, profile, grid_steps, seconds):
 
 def main():
     a = parse()
+    import faulthandler
+    faulthandler.dump_traceback_later(900, exit=True)  # a default run takes well under a minute: never sit in a hang
     import torch                                       # first: libhw_hip.so then shares torch's HIP runtime
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -117,22 +127,57 @@ def main():
     import hwmc
     n_pairs = 1 << a.paths_log2
     p = hwmc.default_params(a.profile, n_steps=a.grid_steps, precision=a.precision)
-    e = hwmc.HullWhiteEngine(p, device=local_rank)
     P, f = hwmc.analytic_curve(p)                      # synthetic market input (exact curve)
-    e.load_market_data(P, f)
-    if a.block:
-        e.set_launch(block_size=a.block)
+    S = max(1, min(a.streams, 8))
+    engines = []
+    for _ in range(S):                                 # one context = one stream + its own partial-sum workspace
+        eng = hwmc.HullWhiteEngine(p, device=local_rank)
+        eng.load_market_data(P, f)
+        if a.block:
+            eng.set_launch(block_size=a.block)
+        engines.append(eng)
+    e = engines[0]
     stepper = hwmc.HW_STEPPER_SUPERPOSED if a.stepper == "superposed" else hwmc.HW_STEPPER_REFERENCE
     K, W = a.steps, a.warmup
     out = torch.zeros((K + W, 5), dtype=torch.float64, device=dev)
-    # An explicit side stream, made torch's CURRENT stream for everything below: the kernels are
-    # enqueued on it through the C ABI, torch's events time it and RCCL orders its all-reduce
+    # Explicit side streams: step i runs on streams[i % S], made torch's CURRENT stream while it is issued, so
+    # the kernels go to it through the C ABI, torch's events time it and RCCL orders that step's all-reduce
     # after it.  (A NULL handle would mean "the context's own stream" to the C ABI.)
-    side = torch.cuda.Stream(device=dev)
+    # HIP multiplexes its streams onto a few hardware queues (4 here) and two streams that share a queue
+    # serialise (tools/queue_map_probe.py: which streams share one depends on the creation history of the whole
+    # process).  So take 8 candidate streams and keep, greedily, those that run the workload fastest together.
+    cands = [torch.cuda.Stream(device=dev) for _ in range(8 if S > 1 else 1)]
+    assert all(st.cuda_stream != 0 for st in cands)
+    pairing = None
+    if S > 1:
+        cal_out = torch.zeros((8, 5), dtype=torch.float64, device=dev)
+
+        def trial(chosen):
+            best = float("inf")
+            for _ in range(3):
+                torch.cuda.synchronize()
+                tc = time.perf_counter()
+                for j in range(8):
+                    engines[j % len(chosen)].enqueue_ZBC(cal_out[j].data_ptr(), n_pairs, 7 + j, stepper=stepper,
+                                                         stream=cands[chosen[j % len(chosen)]].cuda_stream)
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - tc) * 1e3 / 8)
+            return best
+
+        for _ in range(40):                                 # clocks up before comparing anything
+            trial([0])
+        chosen, table = [0], {}
+        while len(chosen) < S:
+            scores = {j: trial(chosen + [j]) for j in range(len(cands)) if j not in chosen}
+            table[len(chosen) + 1] = {str(j): round(v, 4) for j, v in scores.items()}
+            chosen.append(min(scores, key=scores.get))
+        streams = [cands[j] for j in chosen]
+        pairing = {"candidates": len(cands), "chosen": chosen, "ms_per_step_when_added": table,
+                   "ms_per_step_single_stream": round(trial([0]), 4)}
+    else:
+        streams = cands
     torch.cuda.synchronize()
-    torch.cuda.set_stream(side)
-    stream = side.cuda_stream
-    assert stream != 0
+    torch.cuda.set_stream(streams[0])
     # weak scaling: an (N * n_pairs)-pair run, rank g owns the contiguous shard hwmc.parallel.shard gives it
     offset, shard_n = hwmc.parallel.shard(n_pairs * world, rank, world)
     assert shard_n == n_pairs
@@ -141,20 +186,31 @@ def main():
         def wait(self):
             return None
 
+    def enqueue(i, seed, dst, n_streams=S, which=stepper):
+        k = i % n_streams
+        engines[k].enqueue_ZBC(dst.data_ptr(), n_pairs, seed, path_offset=offset, stepper=which,
+                               stream=streams[k].cuda_stream)
+        return k
+
     def step(i, seed):
-        e.enqueue_ZBC(out[i].data_ptr(), n_pairs, seed, path_offset=offset, stepper=stepper, stream=stream)
+        k = enqueue(i, seed, out[i])
         if rehearsal and world > 1:                                     # host round trip, synchronous
-            side.synchronize()
+            streams[k].synchronize()
             tmp = out[i].cpu()
             dist.all_reduce(tmp)
             out[i].copy_(tmp)
             return _Done()
-        return hwmc.parallel.allreduce_sums(out[i], async_op=True)     # None in a single process
+        with torch.cuda.stream(streams[k]):
+            return hwmc.parallel.allreduce_sums(out[i], async_op=True)  # None in a single process
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def join_streams():                                                 # streams[0] waits for the others
+        for st in streams[1:]:
+            streams[0].wait_stream(st)
 
     if world > 1:                                                      # build the communicator outside any timed region
         warm = torch.zeros(5, dtype=torch.float64, device="cpu" if rehearsal else dev)
@@ -163,25 +219,29 @@ def main():
 
     t_spin = time.perf_counter()
     while (time.perf_counter() - t_spin) * 1e3 < a.spinup_ms:      # untimed: bring the clocks up
-        for _ in range(8):
-            e.enqueue_ZBC(out[0].data_ptr(), n_pairs, 7, path_offset=offset, stepper=stepper, stream=stream)
+        for j in range(8):
+            enqueue(j, 7, out[j % (K + W)])
         torch.cuda.synchronize()
     for i in range(W):
         w = step(i, 900 + i)
         if w is not None:
             w.wait()
     fence()
-    # One HIP event pair brackets the K timed launches on the stream they are launched on (torch's
-    # current stream IS that stream): average launch duration = region / K.  Per-launch event pairs
-    # would cost ~7 us of queue bubbles per step, so they are taken in a second, untimed pass below.
+    # One HIP event pair brackets the K timed launches: recorded on streams[0] before the first launch and,
+    # after streams[0] has been made to wait for the other streams, behind the last one.  Per-launch event
+    # pairs are taken in a second, untimed pass below.
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     works = []
+    if os.environ.get("HWMC_BENCH_EVENTS") == "1":
+        for eng in engines:
+            eng.profile_enable(K)
     t0 = time.perf_counter()
-    ev0.record()
+    ev0.record(streams[0])
     for i in range(K):
         works.append(step(W + i, 1234 + 12345 * i))       # seeds as 2_option:229: base + run*12345
-    ev1.record()
+    join_streams()
+    ev1.record(streams[0])
     for w in works:
         if w is not None:
             w.wait()
@@ -192,12 +252,39 @@ def main():
     elapsed = time.perf_counter() - t0
     region_ms = ev0.elapsed_time(ev1)
     sums = out[W:].cpu().numpy()                           # the K all-reduced moment vectors of the timed steps
-    e.profile_enable(K)                                    # untimed pass: isolated per-launch durations
-    scratch = torch.zeros(5, dtype=torch.float64, device=dev)
+    scratch = torch.zeros((K, 5), dtype=torch.float64, device=dev)
+    # untimed pass 1: the same K launches in the same alternation with a hipEvent pair tight around every path
+    # kernel -- the per-launch durations rocprofv3's kernel trace reports for the timed region (with S > 1
+    # two launches share the chip for part of their life, so each one lasts longer than it would alone)
+    if os.environ.get("HWMC_BENCH_EVENTS") == "1":
+        kernel_ms = np.concatenate([eng.profile_read(K) for eng in engines])
+    for eng in engines:
+        eng.profile_enable(K)
     for i in range(K):
-        e.enqueue_ZBC(scratch.data_ptr(), n_pairs, 1234 + 12345 * i, path_offset=offset, stepper=stepper, stream=stream)
+        enqueue(i, 1234 + 12345 * i, scratch[i])
     torch.cuda.synchronize()
-    kernel_ms = e.profile_read(K)
+    kernel_ms2 = np.concatenate([eng.profile_read(K) for eng in engines])
+    if os.environ.get("HWMC_BENCH_EVENTS") == "1":
+        print("events in region: avg %.4f; replay: avg %.4f" % (kernel_ms.mean(), kernel_ms2.mean()), file=sys.stderr)
+    else:
+        kernel_ms = kernel_ms2
+    assert kernel_ms.size == K
+    # untimed pass 2: the same K launches strictly one after another on ONE stream: isolated kernel durations
+    # and the wall-clock rate without pipelining
+    e.profile_enable(K)
+    for i in range(K):
+        enqueue(i, 1234 + 12345 * i, scratch[i], n_streams=1)
+    torch.cuda.synchronize()
+    kernel_ms_isolated = e.profile_read(K)
+    for eng in engines:
+        eng.profile_enable(0)                              # event pairs off: they cost queue bubbles
+    torch.cuda.synchronize()
+    ts = time.perf_counter()
+    for i in range(K):
+        enqueue(i, 1234 + 12345 * i, scratch[i], n_streams=1)
+    torch.cuda.synchronize()
+    serial_ms = (time.perf_counter() - ts) * 1e3 / K
+    assert world > 1 or np.array_equal(scratch.cpu().numpy(), sums), "the stream count changed the sums"
     clock_mhz = e.profile_clock_mhz() if a.stepper == "superposed" else None
     # For the record, the OTHER stepper on the same workload (untimed w.r.t. the headline; N = 1 only): the
     # reference's per-step arithmetic verbatim vs the superposed recursion, so both numbers sit in one line.
@@ -205,12 +292,12 @@ def main():
     if world == 1:
         other = hwmc.HW_STEPPER_REFERENCE if a.stepper == "superposed" else hwmc.HW_STEPPER_SUPERPOSED
         if not (other == hwmc.HW_STEPPER_REFERENCE and a.precision != "f32"):
-            for _ in range(3):
-                e.enqueue_ZBC(scratch.data_ptr(), n_pairs, 5, path_offset=offset, stepper=other, stream=stream)
+            for i in range(3):
+                enqueue(i, 5, scratch[i], which=other)
             torch.cuda.synchronize()
             ta = time.perf_counter()
             for i in range(K):
-                e.enqueue_ZBC(scratch.data_ptr(), n_pairs, 1234 + 12345 * i, path_offset=offset, stepper=other, stream=stream)
+                enqueue(i, 1234 + 12345 * i, scratch[i], which=other)
             torch.cuda.synchronize()
             alt_ms = (time.perf_counter() - ta) * 1e3 / K
             alt = {"stepper": "reference" if other == hwmc.HW_STEPPER_REFERENCE else "superposed",
@@ -228,10 +315,12 @@ def main():
         value = (n_total / ms_per_step) / 1000.0
         steps_exec = int(round(5.0 * a.grid_steps / 10.0))
         info = e.device_info()
-        # Path-kernel duration: hipEvent pairs tight around each of K back-to-back launches (second pass,
-        # same seeds, same stream) -- the quantity rocprofv3's kernel-trace average reports.  The event pair
-        # around the whole timed region additionally contains the 4.7 us column pass and the launch gaps.
+        # Path-kernel duration: hipEvent pairs tight around each of the K launches, replayed in the timed region's
+        # alternation (untimed pass 1) -- the quantity rocprofv3's kernel-trace average reports; kiso is the same
+        # kernel alone on the chip (pass 2).  The event pair around the whole timed region gives the time the GPU
+        # actually spent per step, column pass and launch gaps included: the utilisation figures use that one.
         kavg = float(np.mean(kernel_ms))
+        kiso = float(np.mean(kernel_ms_isolated))
         region_per_step = region_ms / K
         geo_blocks = min((n_pairs + (a.block or 512) - 1) // (a.block or 512), 1 << 20)   # one 256-thread workgroup per 256 pairs (csrc/hw_engine.hip geometry())
         algo_bytes = geo_blocks * 5 * 8 + 5 * 8            # partial rows written + the 5 sums (stateless Philox: no state traffic)
@@ -246,9 +335,11 @@ def main():
         cyc_per_block = 2 * vm["full"] + 4 * vm["half"] + 8 * vm["quarter"]
         waves = (n_pairs + 63) // 64
         simd_cycles = waves * (steps_exec / 4.0) * cyc_per_block
-        valu_frac = simd_cycles / (info["compute_units"] * 4 * info["clock_mhz"] * 1e6 * kavg * 1e-3)
+        simd_hz = info["compute_units"] * 4 * info["clock_mhz"] * 1e6
+        valu_frac = simd_cycles / (simd_hz * region_per_step * 1e-3)        # the chip over the timed region
+        valu_frac_iso = simd_cycles / (simd_hz * kiso * 1e-3)               # one launch alone on the chip
         cyc_meas = sum(MEASURED_ISSUE[k] * vm[k] for k in vm)
-        achieved_cyc = kavg * 1e-3 * (clock_mhz or info["clock_mhz"]) * 1e6 * info["compute_units"] * 4 / (waves * steps_exec / 4.0)
+        achieved_cyc = region_per_step * 1e-3 * (clock_mhz or info["clock_mhz"]) * 1e6 * info["compute_units"] * 4 / (waves * steps_exec / 4.0)
         line = {
             "metric": "M paths/sec (ZBC option, 1000 steps)", "value": round(value, 2), "unit": "M paths/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 5),
@@ -262,32 +353,44 @@ def main():
                        "pairs_per_gpu": n_pairs, "effective_paths": n_total, "grid_steps": a.grid_steps,
                        "steps_executed": steps_exec, "stepper": a.stepper, "theta_profile": a.profile,
                        "rng": "Philox4x32-10 (rocRAND layout), stateless, subsequence = global pair id",
-                       "parallelism": "paths sharded by global id; one RCCL all-reduce of 5 f64 moments per step" if world > 1 else "single GPU"},
+                       "parallelism": "paths sharded by global id; one RCCL all-reduce of 5 f64 moments per step" if world > 1 else "single GPU",
+                       "streams_per_gpu": S, "stream_selection": pairing,
+                       "pipelining": ("the K independent steps alternate over %d contexts/streams per GPU; every step is one full launch" % S)
+                                     if S > 1 else "none: steps run strictly one after another"},
             "thread_steps_per_sec": n_pairs * world * steps_exec / (ms_per_step * 1e-3),
             "price_mean": st["mean"], "ci95_width": st["ci95_width"], "ci95_halfwidth_single_run": prices[0]["ci95_halfwidth"],
             "beta_mean": float(np.mean([r["beta"] for r in prices])),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "zbc_%s_kernel" % a.stepper, "kernel_ms_avg": kavg, "kernel_ms_min": float(np.min(kernel_ms)), "timed_region_ms_per_step_hip_events": region_per_step,
+                         "kernel": "zbc_%s_kernel" % a.stepper, "kernel_ms_avg": kavg, "kernel_ms_min": float(np.min(kernel_ms)),
+                         "kernel_ms_isolated_avg": kiso, "timed_region_ms_per_step_hip_events": region_per_step,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "stateless Philox: the path kernel has ~0 algorithmic HBM traffic; the binding roof is VALU issue (see valu)"},
             "valu": {"bound": "valu-issue", "issue_cycles_per_wave_per_4_steps": cyc_per_block,
                      "instr_per_4_steps": vm, "clock_mhz_nominal": info["clock_mhz"], "frac_of_nominal_clock_peak": valu_frac,
+                     "frac_of_nominal_clock_peak_isolated_launch": valu_frac_iso,
                      "clock_mhz_in_kernel": clock_mhz,
                      "frac_at_measured_clock": (valu_frac * info["clock_mhz"] / clock_mhz) if clock_mhz else None,
                      "measured_issue_cycles_per_op": MEASURED_ISSUE, "issue_cycles_per_4_steps_at_measured_rates": cyc_meas,
                      "achieved_cycles_per_wave_per_4_steps": achieved_cyc, "frac_of_measured_rate_ceiling": cyc_meas / achieved_cyc},
-            "kernel_Mpaths_per_sec": (2 * n_pairs / kavg) / 1000.0,
+            "kernel_Mpaths_per_sec_isolated_launch": (2 * n_pairs / kiso) / 1000.0,
+            "serial": {"streams_per_gpu": 1, "ms_per_step": serial_ms, "value": (2 * n_pairs / serial_ms) / 1000.0,
+                       "unit": "M paths/s per GPU", "note": "same K launches strictly one after another on one stream, no all-reduce"},
             "other_stepper": alt,
             "device": info["name"],
         }
         if rehearsal:
             line["rehearsal"] = "gloo, all ranks on device 0 -- control-flow check only, not a measurement"
         assert 0.0 < st["mean"] < 0.1 and all(np.isfinite(s).all() for s in sums), "implausible reduced sums"
+        if os.environ.get("HWMC_BENCH_TRACE"):
+            print("bench: GPU legs done", file=sys.stderr, flush=True)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(P, f, a.profile, a.grid_steps, a.cpu_seconds)
-        print(json.dumps(line))
-    e.close()
+        print(json.dumps(line), flush=True)
+    for eng in engines:
+        eng.close()
+    if os.environ.get("HWMC_BENCH_TRACE"):
+        print("bench: contexts closed", file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -295,3 +398,5 @@ def main():
 
 if __name__ == "__main__":
     main()
+    if os.environ.get("HWMC_BENCH_TRACE"):
+        print("bench: main returned", file=sys.stderr, flush=True)

@@ -50,6 +50,35 @@ __device__ __forceinline__ PhiloxKey philox_key(uint64_t seed)
     return k;
 }
 
+// a ^ b ^ c in ONE instruction: gfx950's v_bitop3_b32 (any three-input bitwise function, truth table 0x96 =
+// parity) issues at the rate of v_xor_b32 (tools/valu_rates.hip: 2.45 vs 2.47 cycles), so the key-mixing of a
+// Philox round costs 2 instructions instead of 4: 34 -> 19 bitwise ops per block.
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+
+// Round keys 3..10 are consumed by every block of the loop.  HWK_KEYS_IN_VGPRS=1 copies them to vector
+// registers once per thread (an SGPR operand on back-to-back v_bitop3 costs 4.1 cycles instead of 2.45).
+#ifndef HWK_KEYS_IN_VGPRS
+#define HWK_KEYS_IN_VGPRS 1
+#endif
+__device__ __forceinline__ void philox_key_to_vgprs(PhiloxKey& k)
+{
+#if HWK_KEYS_IN_VGPRS
+#pragma unroll
+    for (int r = 2; r < 10; r++) {
+        uint32_t a, b;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(a) : "s"(k.k0[r]));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(b) : "s"(k.k1[r]));
+        k.k0[r] = a;
+        k.k1[r] = b;
+    }
+#else
+    (void)k;
+#endif
+}
+
 __device__ __forceinline__ void mulhilo(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo)
 {
     const uint64_t p = (uint64_t)a * (uint64_t)b;   // one v_mad_u64_u32
@@ -91,7 +120,7 @@ __device__ __forceinline__ void philox_block(const PhiloxKey& k, const PhiloxPat
     c2 = pp.R ^ c3;
     mulhilo(kM0, c0, hi0, lo0);                     // round 3
     mulhilo(kM1, c2, hi1, lo1);
-    c0 = hi1 ^ c1 ^ k.k0[2];
+    c0 = xor3(hi1, c1, k.k0[2]);
     c1 = lo1;
     c2 = hi0 ^ pp.T;
     c3 = lo0;
@@ -99,9 +128,9 @@ __device__ __forceinline__ void philox_block(const PhiloxKey& k, const PhiloxPat
     for (int r = 3; r < 10; r++) {                  // rounds 4..10
         mulhilo(kM0, c0, hi0, lo0);
         mulhilo(kM1, c2, hi1, lo1);
-        c0 = hi1 ^ c1 ^ k.k0[r];
+        c0 = xor3(hi1, c1, k.k0[r]);
         c1 = lo1;
-        c2 = hi0 ^ c3 ^ k.k1[r];
+        c2 = xor3(hi0, c3, k.k1[r]);
         c3 = lo0;
     }
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
@@ -187,7 +216,7 @@ __device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const Phil
     pin2(hi0, hi1);
     HWK_SETPRIO(0);
     pin2(hi0, hi1);
-    c0 = hi1 ^ c1 ^ k.k0[2];
+    c0 = xor3(hi1, c1, k.k0[2]);
     c1 = lo1;
     c2 = hi0 ^ pp.T;
     c3 = lo0;
@@ -201,9 +230,9 @@ __device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const Phil
         pin2(hi0, hi1);
         HWK_SETPRIO(0);
         pin2(hi0, hi1);
-        c0 = hi1 ^ c1 ^ k.k0[r];
+        c0 = xor3(hi1, c1, k.k0[r]);
         c1 = lo1;
-        c2 = hi0 ^ c3 ^ k.k1[r];
+        c2 = xor3(hi0, c3, k.k1[r]);
         c3 = lo0;
     }
     pin4(c0, c1, c2, c3);
@@ -478,6 +507,8 @@ zbc_superposed_kernel(const ZbcArgs<REAL, NSCEN> a, double* __restrict__ partial
     const uint32_t run = blockIdx.x / a.blocks_per_run;
     const uint32_t block_in_run = blockIdx.x - run * a.blocks_per_run;
     const PhiloxKey key = philox_key(a.seed + (uint64_t)run * a.seed_stride);
+    PhiloxKey vkey = key;                           // round keys 3..10 in vector registers for the loop
+    philox_key_to_vgprs(vkey);
     const int64_t T = (int64_t)a.blocks_per_run * blockDim.x;
     const int64_t t = (int64_t)block_in_run * blockDim.x + threadIdx.x;
 
@@ -498,7 +529,7 @@ zbc_superposed_kernel(const ZbcArgs<REAL, NSCEN> a, double* __restrict__ partial
             y[q] = 0;
             S[q] = 0;
         }
-        ou_walk<REAL, ILP>(key, pp, a.n_steps, a.e, y, S);
+        ou_walk<REAL, ILP>(vkey, pp, a.n_steps, a.e, y, S);
 #pragma unroll
         for (int q = 0; q < ILP; q++) {
             const REAL h = S[q] - (REAL)0.5 * y[q];
@@ -553,6 +584,8 @@ zbc_reference_kernel(const ZbcRefArgs a, const float* __restrict__ drift, double
         tab = s_drift;
     }
     const PhiloxKey key = philox_key(a.seed);
+    PhiloxKey vkey = key;                           // round keys 3..10 in vector registers for the loop
+    philox_key_to_vgprs(vkey);
     const int64_t T = (int64_t)gridDim.x * blockDim.x;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     constexpr float kLog2e = 1.4426950408889634f;
@@ -568,7 +601,7 @@ zbc_reference_kernel(const ZbcRefArgs a, const float* __restrict__ drift, double
         HWK_SETPRIO(1);
         for (int i = 0; i < a.n_steps; i += 4) {                     // common.cuh:325-332
             float g[4];
-            normal4_prio(key, pp, (uint32_t)(i >> 2), g);
+            normal4_prio(vkey, pp, (uint32_t)(i >> 2), g);
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 if (i + c < a.n_steps) {
@@ -634,6 +667,8 @@ zcb_curve_kernel(const ZcbArgs<REAL> a, double* __restrict__ partials)
     double* row = s_rows + wave * a.n_mat;
 
     const PhiloxKey key = philox_key(a.seed);
+    PhiloxKey vkey = key;                           // round keys 3..10 in vector registers for the loop
+    philox_key_to_vgprs(vkey);
     const int64_t T = (int64_t)gridDim.x * blockDim.x;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 
@@ -647,7 +682,7 @@ zcb_curve_kernel(const ZcbArgs<REAL> a, double* __restrict__ partials)
         HWK_SETPRIO(1);
         for (int i = 0; i < a.n_steps; i += 4) {
             float g[4];
-            normal4_prio(key, pp, (uint32_t)(i >> 2), g);
+            normal4_prio(vkey, pp, (uint32_t)(i >> 2), g);
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 if (i + c < a.n_steps) {                                   // wave-uniform
@@ -717,6 +752,8 @@ vega_pathwise_kernel(const VegaArgs<REAL> a, double* __restrict__ partials,
 {
     __shared__ double smem[kMaxWaves];
     const PhiloxKey key = philox_key(a.seed);
+    PhiloxKey vkey = key;                           // round keys 3..10 in vector registers for the loop
+    philox_key_to_vgprs(vkey);
     const int64_t T = (int64_t)gridDim.x * blockDim.x;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double acc[1] = {0.0};
@@ -733,7 +770,7 @@ vega_pathwise_kernel(const VegaArgs<REAL> a, double* __restrict__ partials,
             y[q] = 0;
             S[q] = 0;
         }
-        ou_walk<REAL, ILP>(key, pp, a.n_steps, a.e, y, S);
+        ou_walk<REAL, ILP>(vkey, pp, a.n_steps, a.e, y, S);
 #pragma unroll
         for (int q = 0; q < ILP; q++) {
             const REAL h = S[q] - (REAL)0.5 * y[q];
@@ -778,13 +815,15 @@ __global__ void debug_normals_kernel(float* __restrict__ out, uint32_t* __restri
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_blocks) return;
     const PhiloxKey key = philox_key(seed);
+    PhiloxKey vkey = key;                           // round keys 3..10 in vector registers for the loop
+    philox_key_to_vgprs(vkey);
     const PhiloxPath pp = philox_path(key, subseq);
     // exactly what the hot loops consume: the prioritised block and the unscaled Box-Muller, rescaled here
     float g[4];
-    normal4_prio(key, pp, (uint32_t)j, g);
+    normal4_prio(vkey, pp, (uint32_t)j, g);
     for (int c = 0; c < 4; c++) out[4 * j + c] = g[c] * (float)kBmScale;
     uint32_t o[4], h0, h1, h2, h3;
-    philox_block_prio(key, pp, (uint32_t)j, h0, h1, h2, h3);
+    philox_block_prio(vkey, pp, (uint32_t)j, h0, h1, h2, h3);
     HWK_SETPRIO(0);
     philox_block_plain(seed, subseq, (uint64_t)j, o);
     raw[8 * j + 0] = h0; raw[8 * j + 1] = h1; raw[8 * j + 2] = h2; raw[8 * j + 3] = h3;

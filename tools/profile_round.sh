@@ -5,10 +5,12 @@ set -u
 TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
+rm -rf "$OUT"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --spinup-ms 200 --no-cpu-baseline"
+echo "rocprofv3 <--kernel-trace --stats | --pmc ...> -- $BENCH" | sed "s#$ROOT/##" > "$OUT/command.txt"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY \

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of tools/profile_round.sh into the files kept under profiles/.
+
+    python tools/summarize_profile.py gpurun_out/prof_r01 r01 [kernel-name-substring]
+
+Writes profiles/<tag>_bench_kernel_stats.csv (rocprofv3 --stats table, verbatim), and
+profiles/<tag>_pmc_summary.json: per-launch means of every counter for the dominant kernel, the HBM traffic
+corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950, both in KB), and -- from the kernel
+trace -- the launch durations together with the time the kernel actually occupied the chip (union of the
+dispatch intervals / launches), which is what matters when two streams keep two launches in flight."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def newest(pattern):
+    files = glob.glob(pattern, recursive=True)
+    return max(files, key=os.path.getmtime) if files else None
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    want = sys.argv[3] if len(sys.argv) > 3 else "zbc_superposed_kernel<float, 1, 1>"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {"command": open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else None,
+           "kernel": want, "passes": {}}
+    stats = newest(os.path.join(src, "trace", "**", "*kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats, os.path.join(root, "profiles", "%s_bench_kernel_stats.csv" % tag))
+    trace = newest(os.path.join(src, "trace", "**", "*kernel_trace.csv"))
+    if trace:
+        iv = []
+        with open(trace) as fh:
+            for r in csv.DictReader(fh):
+                if want in r["Kernel_Name"]:
+                    iv.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"]))
+        iv.sort()
+        dur = [b - a for a, b, _ in iv]
+        union, cur_a, cur_b = 0, None, None
+        for a, b, _ in iv:
+            if cur_b is None or a > cur_b:
+                if cur_b is not None:
+                    union += cur_b - cur_a
+                cur_a, cur_b = a, b
+            else:
+                cur_b = max(cur_b, b)
+        if cur_b is not None:
+            union += cur_b - cur_a
+        overlapped = sum(1 for i in range(1, len(iv)) if iv[i][0] < max(x[1] for x in iv[max(0, i - 4):i]))
+        out["kernel_trace"] = {
+            "launches": len(iv), "queues": sorted({q for _, _, q in iv}),
+            "avg_duration_us": sum(dur) / len(dur) / 1e3, "min_duration_us": min(dur) / 1e3, "max_duration_us": max(dur) / 1e3,
+            "launches_starting_before_the_previous_one_ended": overlapped,
+            "chip_time_per_launch_us": union / len(iv) / 1e3,
+            "note": "chip_time_per_launch = union of the dispatch intervals / launches: with two queues in flight a "
+                    "dispatch lasts about twice as long as it occupies the chip for",
+        }
+    for pas in ("pmc_sq", "pmc_fetch", "pmc_write"):
+        f = newest(os.path.join(src, pas, "**", "*counter_collection.csv"))
+        if not f:
+            continue
+        acc = {}
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if want in r["Kernel_Name"]:
+                    a = acc.setdefault(r["Counter_Name"], [0, 0.0])
+                    a[0] += 1
+                    a[1] += float(r["Counter_Value"])
+        out["passes"][pas] = {k: {"launches": v[0], "mean_per_launch": v[1] / v[0]} for k, v in sorted(acc.items())}
+    try:
+        fk = out["passes"]["pmc_fetch"]["FETCH_SIZE"]["mean_per_launch"]
+        wk = out["passes"]["pmc_write"]["WRITE_SIZE"]["mean_per_launch"]
+        out["hbm_traffic_bytes_per_launch"] = {
+            "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "corrected_bytes": (2.0 * fk + wk) * 1024.0,
+            "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as read; both in KB"}
+    except KeyError:
+        pass
+    sq = out["passes"].get("pmc_sq", {})
+    if "SQ_INSTS_VALU" in sq and "SQ_WAVES" in sq:
+        out["valu_instructions_per_wave"] = sq["SQ_INSTS_VALU"]["mean_per_launch"] / sq["SQ_WAVES"]["mean_per_launch"]
+    dst = os.path.join(root, "profiles", "%s_pmc_summary.json" % tag)
+    with open(dst, "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out.get("kernel_trace"), indent=1))
+    print(json.dumps(out.get("hbm_traffic_bytes_per_launch"), indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -75,6 +75,9 @@ DEFINE_KERNEL(k_xor_3reg_x2, DECL_U2, INIT_U2, XOR_3REG, SINK_U)
 #define DECL_US unsigned v[kChains]; unsigned k1 = seed * 3u + 0xD2511F53u
 DEFINE_KERNEL(k_xor_sgpr, DECL_US, INIT_U, asm volatile("v_xor_b32 %0, %1, %0" : "+v"(v[c]) : "s"(k1)), SINK_U)
 DEFINE_KERNEL(k_xor_literal, DECL_U, INIT_U, asm volatile("v_xor_b32 %0, 0x9E3779B9, %0" : "+v"(v[c])), SINK_U)
+// gfx950 addition: arbitrary three-input bitwise function; truth table 0x96 = a ^ b ^ c
+DEFINE_KERNEL(k_bitop3_xor3, DECL_U2, INIT_U2, asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(v[c]) : "v"(k1), "v"(k2)), SINK_U)
+DEFINE_KERNEL(k_bitop3_xor3_sgpr, DECL_US, INIT_U, asm volatile("v_bitop3_b32 %0, %0, %1, %0 bitop3:0x96" : "+v"(v[c]) : "s"(k1)), SINK_U)
 #define MAD64S { unsigned long long d; asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(v[c]), "s"(k1) : "vcc"); v[c] = (unsigned)(d >> 32); }
 DEFINE_KERNEL(k_mad_u64_sgpr, DECL_US, INIT_U, MAD64S, SINK_U)
 #define MAD64X { unsigned long long d; asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(v[c]), "s"(k1) : "vcc"); v[c] = (unsigned)(d >> 32) ^ (unsigned)d; }
@@ -114,6 +117,7 @@ int main(int argc, char** argv)
         {"v_mad_u64_u32", k_mad_u64_u32}, {"v_mul_u32_u24", k_mul_u32_u24}, {"v_mul_hi_u32_u24", k_mul_hi_u32_u24},
         {"v_mad_u32_u24", k_mad_u32_u24},
         {"xor d!=a!=b (x2)", k_xor_3reg_x2}, {"xor sgpr,v", k_xor_sgpr}, {"xor literal,v", k_xor_literal},
+        {"bitop3 a^b^c", k_bitop3_xor3}, {"bitop3 a^sgpr^a", k_bitop3_xor3_sgpr},
         {"mad_u64 v*sgpr", k_mad_u64_sgpr}, {"mad_u64+xor(hi,lo)", k_mad_u64_then_xor},
         {"fmamk literal", k_fmamk_literal}, {"mul literal", k_mul_literal}, {"fmac sgpr", k_fmac_sgpr},
     };
