@@ -20,8 +20,11 @@ bit-identical to the single-stream run (tools/overlap_probe.py) and the JSON lin
 single-stream figure ("serial").
 
 N > 1: one process per GPU; rank g prices global pairs [g*n, (g+1)*n) of an N*n-pair run (weak
-scaling), and each step's five moment sums are all-reduced over RCCL (asynchronously, so the
-all-reduce of step i overlaps the kernel of step i+1).  Rank 0 prints ONE JSON line.
+scaling), and the five moment sums of every step are all-reduced over RCCL inside the timed region:
+by default as ONE message of 5*K doubles after the last launch (--allreduce-every B sends one message
+per B steps from a stream of its own; measured with a one-rank communicator that costs 3-6 % because
+RCCL's stream lands on one of the two hardware queues the launches alternate over).  Rank 0 prints ONE
+JSON line.
 """
 import argparse
 import json
@@ -60,6 +63,10 @@ def parse():
     ap.add_argument("--block", type=int, default=0, help="threads per workgroup (0 = engine default)")
     ap.add_argument("--streams", type=int, default=2,
                     help="contexts (HIP streams) per GPU the independent steps alternate over; 1 = strictly serial")
+    ap.add_argument("--allreduce-every", type=int, default=0,
+                    help="N > 1: all-reduce the sums of this many consecutive steps as one message; 0 (default) = ONE "
+                         "all-reduce of all K steps' sums after the last launch, inside the timed region -- the K steps "
+                         "are the reference's 20-run validation, whose statistics need the sums only at the end")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--spinup-ms", type=float, default=400.0,
@@ -117,7 +124,15 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # HWMC_BENCH_FORCE_RCCL=1: run the RCCL code path (communicator, per-step all-reduce ordered after the step's
+    # stream, barriers) even in a single process -- the only way to exercise it on a one-GPU box.
+    dist_on = world > 1 or os.environ.get("HWMC_BENCH_FORCE_RCCL") == "1"
+    if dist_on and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if dist_on:
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -192,19 +207,38 @@ def main():
                                stream=streams[k].cuda_stream)
         return k
 
-    def step(i, seed):
-        k = enqueue(i, seed, out[i])
-        if rehearsal and world > 1:                                     # host round trip, synchronous
-            streams[k].synchronize()
-            tmp = out[i].cpu()
+    # Collectives: the sums of B consecutive steps (--allreduce-every, rows of `out` are contiguous) go out as ONE
+    # all-reduce of 5*B doubles.  It is issued from a stream of its own that waits on an event of every compute
+    # stream, so no compute stream ever waits for another one or for RCCL.
+    B = max(1, a.allreduce_every) if a.allreduce_every > 0 else (K + W)
+    comm_stream = torch.cuda.Stream(device=dev)
+    pending = {"first": None}
+
+    def flush(i_last):
+        i0, pending["first"] = pending["first"], None
+        if i0 is None or not dist_on:
+            return None
+        if rehearsal:                                                   # host round trip, synchronous
+            torch.cuda.synchronize()
+            tmp = out[i0:i_last + 1].cpu()
             dist.all_reduce(tmp)
-            out[i].copy_(tmp)
+            out[i0:i_last + 1].copy_(tmp)
             return _Done()
-        with torch.cuda.stream(streams[k]):
-            return hwmc.parallel.allreduce_sums(out[i], async_op=True)  # None in a single process
+        for st in streams:
+            comm_stream.wait_stream(st)                                 # event record + wait: the compute streams run on
+        with torch.cuda.stream(comm_stream):
+            return hwmc.parallel.allreduce_sums(out[i0:i_last + 1], async_op=True, force=True)
+
+    def step(i, seed, last=False):
+        enqueue(i, seed, out[i])
+        if pending["first"] is None:
+            pending["first"] = i
+        if last or i - pending["first"] + 1 >= B:
+            return flush(i)
+        return None
 
     def fence():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -212,7 +246,7 @@ def main():
         for st in streams[1:]:
             streams[0].wait_stream(st)
 
-    if world > 1:                                                      # build the communicator outside any timed region
+    if dist_on:                                                        # build the communicator outside any timed region
         warm = torch.zeros(5, dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(warm)
         fence()
@@ -223,7 +257,7 @@ def main():
             enqueue(j, 7, out[j % (K + W)])
         torch.cuda.synchronize()
     for i in range(W):
-        w = step(i, 900 + i)
+        w = step(i, 900 + i, last=(i == W - 1))
         if w is not None:
             w.wait()
     fence()
@@ -233,41 +267,32 @@ def main():
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     works = []
-    if os.environ.get("HWMC_BENCH_EVENTS") == "1":
-        for eng in engines:
-            eng.profile_enable(K)
     t0 = time.perf_counter()
     ev0.record(streams[0])
     for i in range(K):
-        works.append(step(W + i, 1234 + 12345 * i))       # seeds as 2_option:229: base + run*12345
+        works.append(step(W + i, 1234 + 12345 * i, last=(i == K - 1)))   # seeds as 2_option:229: base + run*12345
     join_streams()
     ev1.record(streams[0])
     for w in works:
         if w is not None:
             w.wait()
-    torch.cuda.synchronize()
-    if world > 1:
+    torch.cuda.synchronize()                               # every local launch AND every all-reduce has completed, i.e.
+    elapsed = time.perf_counter() - t0                     # every rank has contributed all its K steps; MAX over ranks below
+    if dist_on:
         dist.barrier()
         torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
     region_ms = ev0.elapsed_time(ev1)
     sums = out[W:].cpu().numpy()                           # the K all-reduced moment vectors of the timed steps
     scratch = torch.zeros((K, 5), dtype=torch.float64, device=dev)
     # untimed pass 1: the same K launches in the same alternation with a hipEvent pair tight around every path
     # kernel -- the per-launch durations rocprofv3's kernel trace reports for the timed region (with S > 1
     # two launches share the chip for part of their life, so each one lasts longer than it would alone)
-    if os.environ.get("HWMC_BENCH_EVENTS") == "1":
-        kernel_ms = np.concatenate([eng.profile_read(K) for eng in engines])
     for eng in engines:
         eng.profile_enable(K)
     for i in range(K):
         enqueue(i, 1234 + 12345 * i, scratch[i])
     torch.cuda.synchronize()
-    kernel_ms2 = np.concatenate([eng.profile_read(K) for eng in engines])
-    if os.environ.get("HWMC_BENCH_EVENTS") == "1":
-        print("events in region: avg %.4f; replay: avg %.4f" % (kernel_ms.mean(), kernel_ms2.mean()), file=sys.stderr)
-    else:
-        kernel_ms = kernel_ms2
+    kernel_ms = np.concatenate([eng.profile_read(K) for eng in engines])
     assert kernel_ms.size == K
     # untimed pass 2: the same K launches strictly one after another on ONE stream: isolated kernel durations
     # and the wall-clock rate without pipelining
@@ -302,7 +327,7 @@ def main():
             alt_ms = (time.perf_counter() - ta) * 1e3 / K
             alt = {"stepper": "reference" if other == hwmc.HW_STEPPER_REFERENCE else "superposed",
                    "ms_per_step": alt_ms, "value": (2 * n_pairs / alt_ms) / 1000.0, "unit": "M paths/s"}
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -353,7 +378,8 @@ def main():
                        "pairs_per_gpu": n_pairs, "effective_paths": n_total, "grid_steps": a.grid_steps,
                        "steps_executed": steps_exec, "stepper": a.stepper, "theta_profile": a.profile,
                        "rng": "Philox4x32-10 (rocRAND layout), stateless, subsequence = global pair id",
-                       "parallelism": "paths sharded by global id; one RCCL all-reduce of 5 f64 moments per step" if world > 1 else "single GPU",
+                       "parallelism": ("paths sharded by global id; the 5 f64 moment sums of every step all-reduced over RCCL, %d steps per message" % B)
+                                      if world > 1 else "single GPU",
                        "streams_per_gpu": S, "stream_selection": pairing,
                        "pipelining": ("the K independent steps alternate over %d contexts/streams per GPU; every step is one full launch" % S)
                                      if S > 1 else "none: steps run strictly one after another"},
@@ -391,7 +417,7 @@ def main():
         eng.close()
     if os.environ.get("HWMC_BENCH_TRACE"):
         print("bench: contexts closed", file=sys.stderr, flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -16,9 +16,10 @@ def shard(n_total, rank, world):
     return rank * base + min(rank, rem), base + (1 if rank < rem else 0)
 
 
-def allreduce_sums(t, async_op=False, group=None):
-    """Sum a tensor of moment sums over the ranks in place (no-op in a single process)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+def allreduce_sums(t, async_op=False, group=None, force=False):
+    """Sum a tensor of moment sums over the ranks in place (no-op in a single process unless `force`: a one-rank
+    group still runs the collective, which is how a one-GPU box exercises the RCCL path)."""
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op, group=group)
     return None
 
