@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -71,6 +72,7 @@ struct hw_ctx {
     int table_in_lds = 0;
     int ilp = 1;
     int single_launch = 0;            // 0: path kernel + column pass; 1: in-kernel sharded-ticket finish
+    int curve_generic = 0;            // env HWMC_CURVE_GENERIC=1: always run the per-step curve kernel (A/B tests)
     // optional per-launch event pairs around the path kernel (hw_profile_enable)
     std::vector<hipEvent_t> prof_ev;
     int prof_used = 0, prof_cap = 0;
@@ -108,7 +110,8 @@ inline void prof_mark(hw_ctx* c, hipStream_t st, int which)
 // dispatcher hands them out as CUs free up, which balances the tail better than a residency-sized
 // grid whose threads loop (measured at 2^20 / 2^23 pairs: 0.2245 vs 0.2313 ms, 1.698 vs 1.776 ms).
 // `rows_per_block_bytes` bounds the partials buffer for kernels with wide rows (the curve): their
-// grid is capped at 16 workgroups' worth of waves per CU and the threads loop over the rest.
+// grid is capped at 64 waves' worth of workgroups x 4 per CU (a 26 MB partials buffer at 101 maturities) and the
+// threads loop over the rest.
 Geometry geometry(const hw_ctx* c, int64_t n_units, int ilp, bool wide_rows = false)
 {
     Geometry g{};
@@ -123,12 +126,13 @@ Geometry geometry(const hw_ctx* c, int64_t n_units, int ilp, bool wide_rows = fa
     const int waves_per_block = g.block / 64;
     int64_t cap;
     if (c->max_blocks_per_cu > 0) cap = (int64_t)c->prop.multiProcessorCount * c->max_blocks_per_cu;
-    else if (wide_rows) cap = (int64_t)c->prop.multiProcessorCount * std::max(1, 64 / waves_per_block);
+    else if (wide_rows) cap = (int64_t)c->prop.multiProcessorCount * std::max(1, 256 / waves_per_block);
     else cap = (int64_t)1 << 20;
     g.grid = (int)std::min<int64_t>(want, cap);
     const int64_t per_iter = (int64_t)g.grid * per_block;
     g.iters = (int)((n_units + per_iter - 1) / per_iter);
     if (g.iters < 1) g.iters = 1;
+    g.grid = (int)((want + g.iters - 1) / g.iters);      // same number of iterations, every one of them full
     return g;
 }
 
@@ -311,6 +315,42 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
     for (int j = 1; j < n_mat; j++) scale[j] = std::exp(-cI[(size_t)j * stride]);
     HIP_TRY(hipMemcpyAsync(c->d_scale, scale.data(), n_mat * sizeof(double), hipMemcpyHostToDevice, st));
 
+    // float, whole Philox blocks, maturities on half-block boundaries: the blocked kernel, P pairs per thread
+    // (P = 4 / 2 once the batch still fills the chip's 8 waves per SIMD twice over: measured, one round of fat
+    // threads is no faster than two rounds of thin ones)
+    if (std::is_same<REAL, float>::value && p.n_steps % 4 == 0 && stride % 2 == 0 && stride >= 4 && !c->curve_generic) {
+        const int64_t resident = (int64_t)c->prop.multiProcessorCount * 2048;
+        const int P = n_pairs >= 8 * resident ? 4 : n_pairs >= 4 * resident ? 2 : 1;   // keep >= 2 rounds of waves
+        const Geometry g = geometry(c, n_pairs, P, true);
+        int rc = ensure_partials(c, (size_t)g.grid * n_mat);
+        if (rc) return rc;
+        const double inv = 1.0 / (1.0 - (double)(float)k.e), cz = k.dt * k.sig_st * kLog2e * hwk::kBmScale;
+        hwk::ZcbBlockedArgs a{};
+        a.n_pairs = n_pairs;
+        a.seed = seed;
+        a.path_offset = path_offset;
+        a.n_steps = p.n_steps;
+        a.n_mat = n_mat;
+        a.stride = stride;
+        a.iters = g.iters;
+        a.e = (float)k.e;
+        a.e2 = a.e * a.e;
+        a.c1 = (float)(cz * inv);
+        a.c2 = (float)(cz * ((double)a.e * inv + 0.5));
+        const size_t lds = (size_t)(g.block / 64) * n_mat * sizeof(double);
+        if (lds > 64 * 1024)
+            return fail(HW_E_INVALID, "n_mat = %d needs %zu B of LDS per workgroup at block size %d (limit 65536): use a smaller block", n_mat, lds, g.block);
+        prof_mark(c, st, 0);
+        if (P == 4) hipLaunchKernelGGL(hwk::zcb_curve_blocked_kernel<4>, dim3(g.grid), dim3(g.block), lds, st, a, c->d_partials);
+        else if (P == 2) hipLaunchKernelGGL(hwk::zcb_curve_blocked_kernel<2>, dim3(g.grid), dim3(g.block), lds, st, a, c->d_partials);
+        else hipLaunchKernelGGL(hwk::zcb_curve_blocked_kernel<1>, dim3(g.grid), dim3(g.block), lds, st, a, c->d_partials);
+        prof_mark(c, st, 1);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(n_mat), dim3(256), 0, st, (const double*)c->d_partials,
+                           g.grid, n_mat, 1, (const double*)c->d_scale, 2.0 * (double)n_pairs, d_P_sum, n_mat);
+        HIP_TRY(hipGetLastError());
+        return HW_OK;
+    }
     const Geometry g = geometry(c, n_pairs, 1, true);
     int rc = ensure_partials(c, (size_t)g.grid * n_mat);
     if (rc) return rc;
@@ -470,6 +510,7 @@ int hw_create(const hw_params* p, int device, hw_ctx** out)
     if (e == hipSuccess) e = hipMalloc(&c->d_ticket, 9 * hwk::kTicketStride * sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(c->d_ticket, 0, 9 * hwk::kTicketStride * sizeof(unsigned));
     if (const char* m = getenv("HWMC_SINGLE_LAUNCH")) c->single_launch = atoi(m) ? 1 : 0;
+    if (const char* m = getenv("HWMC_CURVE_GENERIC")) c->curve_generic = atoi(m) ? 1 : 0;
     if (e != hipSuccess) {
         hw_destroy(c);
         return fail(HW_E_HIP, "hw_create: %s", hipGetErrorString(e));

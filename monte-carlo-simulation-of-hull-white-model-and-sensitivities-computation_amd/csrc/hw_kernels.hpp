@@ -771,6 +771,97 @@ zcb_curve_kernel(const ZcbArgs<REAL> a, double* __restrict__ partials)
     }
 }
 
+// Blocked float form of the curve kernel (n_steps % 4 == 0, stride even and >= 4; everything else runs the
+// generic kernel above).  Two changes against it:
+//   * the steps advance half a Philox block (= one Box-Muller pair = 2 steps) at a time in the (y, W) form of
+//     ou_walk: 5 single-rate ops per two steps instead of 6, and a maturity (every stride/2 half blocks) always
+//     falls on a half-block boundary;  z = cz (S - y/2) = c1 W - c2 y with c1 = cz/(1-e), c2 = cz (e/(1-e) + 1/2);
+//   * every thread carries P pairs through the time loop together, so the per-maturity wave reduction and LDS
+//     update (6 DPP adds + an LDS read-modify-write, ~50 of the ~85 issue cycles a maturity costs a wave) is paid
+//     once per P pairs: the P values are added per lane first.
+struct ZcbBlockedArgs {
+    int64_t n_pairs;
+    uint64_t seed, path_offset;
+    int32_t n_steps, n_mat, stride, iters;
+    float e, e2, c1, c2;
+};
+
+template <int P>
+__global__ void __launch_bounds__(1024)
+zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
+{
+    extern __shared__ double s_rows[];                 // [nwaves][n_mat]
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int nwaves = (blockDim.x + kWave - 1) >> 6;
+    for (int i = threadIdx.x; i < nwaves * a.n_mat; i += blockDim.x) s_rows[i] = 0.0;
+    __syncthreads();
+    double* row = s_rows + wave * a.n_mat;
+
+    const PhiloxKey key = philox_key(a.seed);
+    PhiloxKey vkey = key;
+    philox_key_to_vgprs(vkey);
+    const int64_t T = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nblk = a.n_steps >> 2, half_stride = a.stride >> 1;
+
+    for (int it = 0; it < a.iters; it++) {
+        PhiloxPath pp[P];
+        float y[P], W[P], live[P];
+#pragma unroll
+        for (int q = 0; q < P; q++) {
+            int64_t p = t + ((int64_t)it * P + q) * T;
+            live[q] = p < a.n_pairs ? 1.0f : 0.0f;
+            if (p >= a.n_pairs) p = 0;
+            pp[q] = philox_path(key, a.path_offset + (uint64_t)p);
+            y[q] = 0.0f;
+            W[q] = 0.0f;
+        }
+        int to_event = half_stride, m = 0;             // half blocks until the next maturity
+        HWK_SETPRIO(1);
+        for (int j = 0; j < nblk; j++) {
+            const int ev = to_event <= 2 ? to_event : 0;                   // 1: after the first half, 2: after the second
+            float accq = 0.0f;
+#pragma unroll
+            for (int q = 0; q < P; q++) {
+                uint32_t w0, w1, w2, w3;
+                philox_block_prio(vkey, pp[q], (uint32_t)j, w0, w1, w2, w3);
+                float s0, sn0, cs0, s1, sn1, cs1;
+                box_muller_parts(w0, w1, s0, sn0, cs0);
+                box_muller_parts(w2, w3, s1, sn1, cs1);
+                y[q] = __builtin_fmaf(a.e2, y[q], s0 * __builtin_fmaf(a.e, sn0, cs0));
+                W[q] = __builtin_fmaf(s0, sn0 + cs0, W[q]);
+                if (ev == 1) {                                             // wave-uniform
+                    const float z = __builtin_fmaf(a.c1, W[q], -a.c2 * y[q]);
+                    accq = __builtin_fmaf(live[q], hw_exp2(z) + hw_exp2(-z), accq);     // market_data.cuh:60
+                }
+                y[q] = __builtin_fmaf(a.e2, y[q], s1 * __builtin_fmaf(a.e, sn1, cs1));
+                W[q] = __builtin_fmaf(s1, sn1 + cs1, W[q]);
+                if (ev == 2) {
+                    const float z = __builtin_fmaf(a.c1, W[q], -a.c2 * y[q]);
+                    accq = __builtin_fmaf(live[q], hw_exp2(z) + hw_exp2(-z), accq);
+                }
+            }
+            if (ev) {
+                m++;
+                if (m < a.n_mat) {                                         // market_data.cuh:59
+                    const float qs = wave_sum_to_lane63(accq);             // market_data.cuh:61
+                    if (lane == kWave - 1) row[m] += (double)qs;           // market_data.cuh:62-64
+                }
+                to_event = half_stride - (2 - ev);
+            } else {
+                to_event -= 2;
+            }
+        }
+        HWK_SETPRIO(0);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < a.n_mat; k += blockDim.x) {
+        double tsum = 0.0;
+        for (int w = 0; w < nwaves; w++) tsum += s_rows[w * a.n_mat + k];
+        partials[(size_t)blockIdx.x * a.n_mat + k] = tsum;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Pathwise Vega: d_sigma r follows the same OU recursion with its own drift and shock
 // (s/sigma) G (3_sens:54-61), so  d_sigma r_i = D_i + (s/sigma) y_i  with the SAME y.

@@ -390,3 +390,35 @@ def test_comm_one_device_equals_single_context(setup, hwmc_mod):
         assert np.array_equal(fleet.simulate_ZBC_control_variate(0, 1), np.zeros(5))
     with pytest.raises(hwmc_mod.HwError):
         hwmc_mod.HullWhiteFleet([e, e])                                             # one device twice
+
+
+# ---- curve kernel variants ---------------------------------------------------------------------------
+def test_zcb_curve_blocked_kernel_variants(hwmc_mod, oracle_mod, monkeypatch):
+    """The float curve runs a blocked kernel (half Philox blocks, P pairs per thread: P = 1 below 2^21 pairs, 2
+    from 2^21, 4 from 2^22 on a 256-CU chip) and falls back to the per-step kernel when a maturity cannot fall on a
+    half-block boundary (odd stride).  All of them against the oracle, and against the per-step kernel forced by
+    HWMC_CURVE_GENERIC=1 (read when the context is created)."""
+    p = hwmc_mod.default_params("readme")
+    o = oracle_mod.Oracle("readme")
+    e = hwmc_mod.HullWhiteEngine(p, device=0)
+    monkeypatch.setenv("HWMC_CURVE_GENERIC", "1")
+    g = hwmc_mod.HullWhiteEngine(p, device=0)
+    monkeypatch.delenv("HWMC_CURVE_GENERIC")
+    cus = e.device_info()["compute_units"]
+    for n in (1000, 4 * 2048 * cus + 77, 8 * 2048 * cus + 5):                      # P = 1, 2, 4 (ragged counts)
+        got = e.simulate_zcb(n, 11)
+        assert got[0] == 2.0 * n
+        np.testing.assert_allclose(got, g.simulate_zcb(n, 11), rtol=2e-6)           # two float evaluation orders
+        if n <= 4 * 2048 * cus + 77:
+            np.testing.assert_allclose(got, o.zcb_curve(n, 11), rtol=REL_F32)
+        half = n // 2                                                              # shards add up (other P per shard)
+        parts = e.simulate_zcb(half, 11) + e.simulate_zcb(n - half, 11, path_offset=half)
+        np.testing.assert_allclose(got[1:], parts[1:], rtol=1e-6)
+    e.close()
+    g.close()
+    # odd stride (1000 steps, 201 maturities -> every 5 steps): per-step kernel
+    p5 = hwmc_mod.default_params("readme", n_mat=201)
+    e5 = hwmc_mod.HullWhiteEngine(p5, device=0)
+    o5 = oracle_mod.Oracle("readme", n_mat=201)
+    np.testing.assert_allclose(e5.simulate_zcb(2000, 4), o5.zcb_curve(2000, 4), rtol=REL_F32)
+    e5.close()
