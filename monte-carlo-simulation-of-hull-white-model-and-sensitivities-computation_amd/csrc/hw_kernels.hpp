@@ -307,6 +307,28 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
+// The same for a double: both halves travel through the DPP network (2 v_mov_b32_dpp + 1 v_add_f64 per step;
+// the ds_bpermute form of __shfl_down costs two LDS-crossbar round trips of ~100 cycles per step, and the five
+// sums of the ZBC epilogue made 60 of them per wave: tools/fixed_cost_probe.py).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(unsigned long long)b, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double v)
+{
+    v += dpp_mov<0xB1, 0xf>(v);
+    v += dpp_mov<0x4E, 0xf>(v);
+    v += dpp_mov<0x141, 0xf>(v);
+    v += dpp_mov<0x140, 0xf>(v);
+    v += dpp_mov<0x142, 0xa>(v);
+    v += dpp_mov<0x143, 0xc>(v);
+    return v;
+}
+
 // Finish of a sum over the whole grid.  Every workgroup reduces its threads' N values (lane tree,
 // waves in index order) and stores one row of partials.  What happens next is chosen by the host
 // through the `ticket` argument:
@@ -334,8 +356,8 @@ __device__ __forceinline__ void grid_sum_finish(double (&v)[N], double* smem /*[
     const int nwaves = (blockDim.x + kWave - 1) >> 6;
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        const double s = wave_sum(v[k]);
-        if (lane == 0) smem[wave * N + k] = s;
+        const double s = wave_sum_to_lane63(v[k]);
+        if (lane == kWave - 1) smem[wave * N + k] = s;
     }
     __syncthreads();
     if (wave != 0 && ticket == nullptr) return;
@@ -698,12 +720,7 @@ zbc_reference_kernel(const ZbcRefArgs a, const float* __restrict__ drift, double
 // Per-wave running sums live in LDS as doubles: row [wave][n_mat], touched by lane 0 only.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float  curve_wave_sum(float q)  { return wave_sum_to_lane63(q); }
-__device__ __forceinline__ double curve_wave_sum(double q)
-{   // total broadcast to every lane (xor butterfly), so lane 63 holds it too
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) q += __shfl_xor(q, off, kWave);
-    return q;
-}
+__device__ __forceinline__ double curve_wave_sum(double q) { return wave_sum_to_lane63(q); }
 
 template <typename REAL>
 struct ZcbArgs {
