@@ -39,8 +39,8 @@ sys.path.insert(0, ROOT)
 # (instruction counts from the gfx950 disassembly -- tools/loop_census.py --, issue cycles per wave64 instruction per SIMD
 #  measured by tools/valu_rates.hip on MI355X: full rate 2, half rate 4, quarter rate 8).
 VALU_MODEL = {
-    "superposed": {"full": 31, "half": 22, "quarter": 8},   # 15 bitop3,4 xor,4 fmamk,2 mul,4 fma/fmac,2 add | 17 mad_u64,4 cvt,1 pk_fma | 2 log,2 sqrt,2 sin,2 cos
-    "reference": {"full": 64, "half": 21, "quarter": 8},    # + per-step: sG mul, 2 add, 2 fma, 2 add, 2 mul/fma pairs on two legs
+    "superposed": {"full": 30, "half": 21, "quarter": 8},   # 14 bitop3,4 xor,4 fmamk,2 mul,4 fma/fmac,2 add | 16 mad_u64,4 cvt,1 pk_fma | 2 log,2 sqrt,2 sin,2 cos
+    "reference": {"full": 64, "half": 21, "quarter": 8},    # (per-lane round-2 multiply: 17 mad_u64)    # + per-step: sG mul, 2 add, 2 fma, 2 add, 2 mul/fma pairs on two legs
 }
 # Issue costs measured on MI355X at 8 waves/SIMD (tools/valu_rates.hip, tools/valu_patterns.hip; profiles/):
 # "full-rate" ops sustain one per 2.3 cycles (two waves issue side by side; one wave alone: 4.7),

@@ -16,6 +16,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace hwk {
 
@@ -34,6 +35,7 @@ constexpr uint32_t kM0 = 0xD2511F53u, kM1 = 0xCD9E8D57u, kW0 = 0x9E3779B9u, kW1 
 
 struct PhiloxKey {
     uint32_t k0[10], k1[10];
+    uint32_t s_k0_2;      // k0[2] again: stays in an SGPR when philox_key_to_vgprs() moves k0[2..9], k1[2..9]
 };
 
 __device__ __forceinline__ PhiloxKey philox_key(uint64_t seed)
@@ -47,6 +49,7 @@ __device__ __forceinline__ PhiloxKey philox_key(uint64_t seed)
         a += kW0;
         b += kW1;
     }
+    k.s_k0_2 = k.k0[2];
     return k;
 }
 
@@ -200,23 +203,43 @@ __device__ __forceinline__ void pin4(uint32_t& a, uint32_t& b, uint32_t& c, uint
 // Same words as philox_block().  Entered AND left at priority 1: the caller's Box-Muller + steps run
 // there, and so do the three multiplies of rounds 2-3 (measured: 272 -> 265 cycles per block against
 // dropping the priority at block entry); the xors run at priority 0.
-__device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const PhiloxPath& pp, uint32_t j,
+//
+// UHI = true: the HIGH word of the path id is the same in every lane of the wave (a2s = that word ^ k1[0], in
+// an SGPR) -- true for every wave that does not straddle a multiple of 2^32 paths.  Then word 2 after round 1,
+// hi(M0 j) ^ phi ^ k1[0], is wave-uniform as well, and the M1 multiply of round 2 runs on the scalar unit:
+// 16 vector multiplies and 18 bitwise ops per block instead of 17 and 19.
+template <bool UHI>
+__device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const PhiloxPath& pp, uint32_t a2s, uint32_t j,
                                                   uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
 {
     uint32_t hi0, lo0, hi1, lo1;
     mulhilo(kM0, j, hi0, lo0);                      // round 1 (scalar)
-    uint32_t c2 = pp.A2 ^ hi0;
-    uint32_t c3 = lo0;
-    mulhilo(kM1, c2, hi1, lo1);                     // round 2
-    uint32_t c0 = hi1 ^ pp.Q;
-    uint32_t c1 = lo1;
-    c2 = pp.R ^ c3;
-    mulhilo(kM0, c0, hi0, lo0);                     // round 3
-    mulhilo(kM1, c2, hi1, lo1);
-    pin2(hi0, hi1);
-    HWK_SETPRIO(0);
-    pin2(hi0, hi1);
-    c0 = xor3(hi1, c1, k.k0[2]);
+    uint32_t c0, c1, c2, c3;
+    if constexpr (UHI) {
+        uint32_t shi, slo;
+        mulhilo(kM1, a2s ^ hi0, shi, slo);          // round 2, word-2 product (scalar)
+        c0 = shi ^ pp.Q;
+        c2 = pp.R ^ lo0;
+        mulhilo(kM0, c0, hi0, lo0);                 // round 3
+        mulhilo(kM1, c2, hi1, lo1);
+        pin2(hi0, hi1);
+        HWK_SETPRIO(0);
+        pin2(hi0, hi1);
+        c0 = hi1 ^ (slo ^ k.s_k0_2);
+    } else {
+        c2 = pp.A2 ^ hi0;
+        c3 = lo0;
+        mulhilo(kM1, c2, hi1, lo1);                 // round 2
+        c0 = hi1 ^ pp.Q;
+        c1 = lo1;
+        c2 = pp.R ^ c3;
+        mulhilo(kM0, c0, hi0, lo0);                 // round 3
+        mulhilo(kM1, c2, hi1, lo1);
+        pin2(hi0, hi1);
+        HWK_SETPRIO(0);
+        pin2(hi0, hi1);
+        c0 = xor3(hi1, c1, k.k0[2]);
+    }
     c1 = lo1;
     c2 = hi0 ^ pp.T;
     c3 = lo0;
@@ -240,6 +263,18 @@ __device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const Phil
     pin4(c0, c1, c2, c3);
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
+__device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const PhiloxPath& pp, uint32_t j,
+                                                  uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
+{
+    philox_block_prio<false>(k, pp, 0u, j, o0, o1, o2, o3);
+}
+
+// Is the high word of the path id the same in all lanes?  Returns it (xor k1[0]) in an SGPR.
+__device__ __forceinline__ bool philox_uniform_hi(const PhiloxPath& pp, uint32_t& a2s)
+{
+    a2s = __builtin_amdgcn_readfirstlane(pp.A2);
+    return __builtin_amdgcn_ballot_w64(pp.A2 != a2s) == 0;
+}
 
 // Box-Muller with the constant factor of the radius left out: sqrt(-2 ln u) = kBmScale * sqrt(-log2 u),
 // kBmScale = sqrt(2 ln 2).  The hot loops run their linear recursions on n / kBmScale and the host folds
@@ -257,12 +292,17 @@ __device__ __forceinline__ void box_muller_unscaled(uint32_t x, uint32_t y, floa
 }
 
 // The four normals of block j, divided by kBmScale, for the hot loops; exits at priority 1.
-__device__ __forceinline__ void normal4_prio(const PhiloxKey& k, const PhiloxPath& pp, uint32_t j, float (&g)[4])
+template <bool UHI>
+__device__ __forceinline__ void normal4_prio(const PhiloxKey& k, const PhiloxPath& pp, uint32_t a2s, uint32_t j, float (&g)[4])
 {
     uint32_t w0, w1, w2, w3;
-    philox_block_prio(k, pp, j, w0, w1, w2, w3);
+    philox_block_prio<UHI>(k, pp, a2s, j, w0, w1, w2, w3);
     box_muller_unscaled(w0, w1, g[0], g[1]);
     box_muller_unscaled(w2, w3, g[2], g[3]);
+}
+__device__ __forceinline__ void normal4_prio(const PhiloxKey& k, const PhiloxPath& pp, uint32_t j, float (&g)[4])
+{
+    normal4_prio<false>(k, pp, 0u, j, g);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -478,27 +518,36 @@ __device__ __forceinline__ void ou_walk(const PhiloxKey& key, const PhiloxPath (
 {
     const int nblk = n_steps >> 2;
     const int rem = n_steps & 3;
+    uint32_t a2s[ILP];
+    bool uhi = true;                                  // wave-uniform: see philox_block_prio<UHI>
+#pragma unroll
+    for (int q = 0; q < ILP; q++) uhi = philox_uniform_hi(pp[q], a2s[q]) && uhi;
     HWK_SETPRIO(1);
     if constexpr (sizeof(REAL) == sizeof(float)) {
         const float e2 = e * e;
         float W[ILP];
 #pragma unroll
         for (int q = 0; q < ILP; q++) W[q] = 0.0f;
-        for (int j = 0; j < nblk; j++) {
+        auto blocks = [&](auto tag) {
+            constexpr bool UHI = decltype(tag)::value;
+            for (int j = 0; j < nblk; j++) {
 #pragma unroll
-            for (int q = 0; q < ILP; q++) {
-                uint32_t w0, w1, w2, w3;
-                philox_block_prio(key, pp[q], (uint32_t)j, w0, w1, w2, w3);
-                float s0, sn0, cs0, s1, sn1, cs1;
-                box_muller_parts(w0, w1, s0, sn0, cs0);
-                box_muller_parts(w2, w3, s1, sn1, cs1);
-                const float a0 = __builtin_fmaf(e, sn0, cs0), a1 = __builtin_fmaf(e, sn1, cs1);
-                const float b0 = sn0 + cs0, b1 = sn1 + cs1;
-                const float t = __builtin_fmaf(e2, y[q], s0 * a0);
-                y[q] = __builtin_fmaf(e2, t, s1 * a1);
-                W[q] = __builtin_fmaf(s1, b1, __builtin_fmaf(s0, b0, W[q]));
+                for (int q = 0; q < ILP; q++) {
+                    uint32_t w0, w1, w2, w3;
+                    philox_block_prio<UHI>(key, pp[q], a2s[q], (uint32_t)j, w0, w1, w2, w3);
+                    float s0, sn0, cs0, s1, sn1, cs1;
+                    box_muller_parts(w0, w1, s0, sn0, cs0);
+                    box_muller_parts(w2, w3, s1, sn1, cs1);
+                    const float a0 = __builtin_fmaf(e, sn0, cs0), a1 = __builtin_fmaf(e, sn1, cs1);
+                    const float b0 = sn0 + cs0, b1 = sn1 + cs1;
+                    const float t = __builtin_fmaf(e2, y[q], s0 * a0);
+                    y[q] = __builtin_fmaf(e2, t, s1 * a1);
+                    W[q] = __builtin_fmaf(s1, b1, __builtin_fmaf(s0, b0, W[q]));
+                }
             }
-        }
+        };
+        if (uhi) blocks(std::true_type{});
+        else blocks(std::false_type{});
         if (rem) {                                    // wave-uniform tail: 1..3 single steps
 #pragma unroll
             for (int q = 0; q < ILP; q++) {
@@ -517,18 +566,23 @@ __device__ __forceinline__ void ou_walk(const PhiloxKey& key, const PhiloxPath (
 #pragma unroll
         for (int q = 0; q < ILP; q++) S[q] = (W[q] - e * y[q]) * inv;
     } else {
-        for (int j = 0; j < nblk; j++) {
+        auto blocks = [&](auto tag) {
+            constexpr bool UHI = decltype(tag)::value;
+            for (int j = 0; j < nblk; j++) {
 #pragma unroll
-            for (int q = 0; q < ILP; q++) {
-                float g[4];
-                normal4_prio(key, pp[q], (uint32_t)j, g);
+                for (int q = 0; q < ILP; q++) {
+                    float g[4];
+                    normal4_prio<UHI>(key, pp[q], a2s[q], (uint32_t)j, g);
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    y[q] = hw_fma(y[q], e, (REAL)g[c]);
-                    S[q] += y[q];
+                    for (int c = 0; c < 4; c++) {
+                        y[q] = hw_fma(y[q], e, (REAL)g[c]);
+                        S[q] += y[q];
+                    }
                 }
             }
-        }
+        };
+        if (uhi) blocks(std::true_type{});
+        else blocks(std::false_type{});
         if (rem) {                                    // wave-uniform tail
 #pragma unroll
             for (int q = 0; q < ILP; q++) {
@@ -833,42 +887,51 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
             y[q] = 0.0f;
             W[q] = 0.0f;
         }
-        int to_event = half_stride, m = 0;             // half blocks until the next maturity
-        HWK_SETPRIO(1);
-        for (int j = 0; j < nblk; j++) {
-            const int ev = to_event <= 2 ? to_event : 0;                   // 1: after the first half, 2: after the second
-            float accq = 0.0f;
+        uint32_t a2s[P];
+        bool uhi = true;
 #pragma unroll
-            for (int q = 0; q < P; q++) {
-                uint32_t w0, w1, w2, w3;
-                philox_block_prio(vkey, pp[q], (uint32_t)j, w0, w1, w2, w3);
-                float s0, sn0, cs0, s1, sn1, cs1;
-                box_muller_parts(w0, w1, s0, sn0, cs0);
-                box_muller_parts(w2, w3, s1, sn1, cs1);
-                y[q] = __builtin_fmaf(a.e2, y[q], s0 * __builtin_fmaf(a.e, sn0, cs0));
-                W[q] = __builtin_fmaf(s0, sn0 + cs0, W[q]);
-                if (ev == 1) {                                             // wave-uniform
-                    const float z = __builtin_fmaf(a.c1, W[q], -a.c2 * y[q]);
-                    accq = __builtin_fmaf(live[q], hw_exp2(z) + hw_exp2(-z), accq);     // market_data.cuh:60
+        for (int q = 0; q < P; q++) uhi = philox_uniform_hi(pp[q], a2s[q]) && uhi;
+        HWK_SETPRIO(1);
+        auto blocks = [&](auto tag) {
+            constexpr bool UHI = decltype(tag)::value;
+            int to_event = half_stride, m = 0;         // half blocks until the next maturity
+            for (int j = 0; j < nblk; j++) {
+                const int ev = to_event <= 2 ? to_event : 0;               // 1: after the first half, 2: after the second
+                float accq = 0.0f;
+#pragma unroll
+                for (int q = 0; q < P; q++) {
+                    uint32_t w0, w1, w2, w3;
+                    philox_block_prio<UHI>(vkey, pp[q], a2s[q], (uint32_t)j, w0, w1, w2, w3);
+                    float s0, sn0, cs0, s1, sn1, cs1;
+                    box_muller_parts(w0, w1, s0, sn0, cs0);
+                    box_muller_parts(w2, w3, s1, sn1, cs1);
+                    y[q] = __builtin_fmaf(a.e2, y[q], s0 * __builtin_fmaf(a.e, sn0, cs0));
+                    W[q] = __builtin_fmaf(s0, sn0 + cs0, W[q]);
+                    if (ev == 1) {                                         // wave-uniform
+                        const float z = __builtin_fmaf(a.c1, W[q], -a.c2 * y[q]);
+                        accq = __builtin_fmaf(live[q], hw_exp2(z) + hw_exp2(-z), accq);     // market_data.cuh:60
+                    }
+                    y[q] = __builtin_fmaf(a.e2, y[q], s1 * __builtin_fmaf(a.e, sn1, cs1));
+                    W[q] = __builtin_fmaf(s1, sn1 + cs1, W[q]);
+                    if (ev == 2) {
+                        const float z = __builtin_fmaf(a.c1, W[q], -a.c2 * y[q]);
+                        accq = __builtin_fmaf(live[q], hw_exp2(z) + hw_exp2(-z), accq);
+                    }
                 }
-                y[q] = __builtin_fmaf(a.e2, y[q], s1 * __builtin_fmaf(a.e, sn1, cs1));
-                W[q] = __builtin_fmaf(s1, sn1 + cs1, W[q]);
-                if (ev == 2) {
-                    const float z = __builtin_fmaf(a.c1, W[q], -a.c2 * y[q]);
-                    accq = __builtin_fmaf(live[q], hw_exp2(z) + hw_exp2(-z), accq);
+                if (ev) {
+                    m++;
+                    if (m < a.n_mat) {                                     // market_data.cuh:59
+                        const float qs = wave_sum_to_lane63(accq);         // market_data.cuh:61
+                        if (lane == kWave - 1) row[m] += (double)qs;       // market_data.cuh:62-64
+                    }
+                    to_event = half_stride - (2 - ev);
+                } else {
+                    to_event -= 2;
                 }
             }
-            if (ev) {
-                m++;
-                if (m < a.n_mat) {                                         // market_data.cuh:59
-                    const float qs = wave_sum_to_lane63(accq);             // market_data.cuh:61
-                    if (lane == kWave - 1) row[m] += (double)qs;           // market_data.cuh:62-64
-                }
-                to_event = half_stride - (2 - ev);
-            } else {
-                to_event -= 2;
-            }
-        }
+        };
+        if (uhi) blocks(std::true_type{});
+        else blocks(std::false_type{});
         HWK_SETPRIO(0);
     }
     __syncthreads();

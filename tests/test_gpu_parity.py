@@ -146,6 +146,15 @@ def test_zbc_edge_cases_and_sharding(setup, hwmc_mod):
     for n in (63, 64, 65, 255, 257, 1000):
         got = e.simulate_ZBC_control_variate(n, 3, path_offset=2 ** 40 + 17)
         np.testing.assert_allclose(got, o.zbc_moments(P, f, n, 3, path_offset=2 ** 40 + 17), rtol=REL_F32)
+    # waves that straddle a multiple of 2^32 pair ids (the lanes' high id words differ: the kernels then leave the
+    # scalar round-2 multiply of philox_block_prio<UHI> for the per-lane form) and waves just beside one
+    for off in (2 ** 32 - 30, 2 ** 32 - 64, 2 ** 32, 2 ** 33 - 1000):
+        got = e.simulate_ZBC_control_variate(2000, 5, path_offset=off)
+        np.testing.assert_allclose(got, o.zbc_moments(P, f, 2000, 5, path_offset=off), rtol=REL_F32)
+    np.testing.assert_allclose(e.simulate_zcb(300, 5, path_offset=2 ** 32 - 100),
+                               o.zcb_curve(300, 5, path_offset=2 ** 32 - 100), rtol=REL_F32)
+    assert e.simulate_sensitivity(300, 5, path_offset=2 ** 32 - 100) == pytest.approx(
+        o.vega_pathwise(P, f, 300, 5, path_offset=2 ** 32 - 100), rel=REL_F32)
     # shards by path_offset add up to the whole (what the multi-GPU path relies on)
     whole = e.simulate_ZBC_control_variate(10000, 9)
     parts = sum(e.simulate_ZBC_control_variate(m, 9, path_offset=off)

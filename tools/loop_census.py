@@ -3,7 +3,7 @@
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S -o eng.s <package>/csrc/hw_engine.hip
     python tools/loop_census.py eng.s zbc_superposed_kernelIfLi1ELi1E
-Finds the kernel whose mangled name contains the pattern, takes its innermost loop with the most wide multiplies and counts
+Finds the kernel whose mangled name contains the pattern, takes its innermost loops with at least 10 wide multiplies and counts
 opcodes (the numbers quoted in DESIGN.md section 5 and in bench.py's VALU_MODEL come from here)."""
 import re
 import sys
@@ -29,13 +29,15 @@ def main():
         if mm and mm.group(1) in labels and labels[mm.group(1)] <= i:
             spans.append((labels[mm.group(1)], i))
     inner = [a for a in spans if not any(b != a and a[0] <= b[0] and b[1] <= a[1] for b in spans)]
-    best = max(inner, key=lambda sp: sum("v_mad_u64_u32" in x for x in lines[sp[0]:sp[1] + 1]))
-    loop = [l.strip() for l in lines[best[0]:best[1] + 1] if l.strip() and not l.strip().startswith((";", "."))]
-    c = Counter(l.split()[0] for l in loop)
+    hot = [sp for sp in inner if sum("v_mad_u64_u32" in x for x in lines[sp[0]:sp[1] + 1]) >= 10]
     print(m.group(1))
-    print(len(loop), "instructions in the hot loop")
-    for k, v in sorted(c.items(), key=lambda kv: (-kv[1], kv[0])):
-        print(f"  {k:24s} {v}")
+    for best in hot:                       # a kernel may hold several copies of the loop (e.g. the uniform-high-word one)
+        loop = [l.strip() for l in lines[best[0]:best[1] + 1] if l.strip() and not l.strip().startswith((";", "."))]
+        c = Counter(l.split()[0] for l in loop)
+        print(len(loop), "instructions in hot loop", lines[best[0]].strip().split(":")[0])
+        for k, v in sorted(c.items(), key=lambda kv: (-kv[1], kv[0])):
+            if not k.startswith("s_") or len(sys.argv) > 3:
+                print(f"  {k:24s} {v}")
     tail = s[m.end():m.end() + 6000]
     for k in ("NumVgprs", "NumSgprs", "ScratchSize", "Occupancy"):
         mm = re.search(r"; %s: (\d+)" % k, tail)
