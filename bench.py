@@ -75,43 +75,13 @@ def parse():
     return ap.parse_args()
 
 
-def usable_cores(omp_max):
-    """Threads worth starting: the smallest of OpenMP's default, the affinity mask and the cgroup CPU quota
-    (a GPU box hands a job a share of the host's cores; more threads than that only get throttled)."""
-    n, how = omp_max, "omp_get_max_threads"
-    try:
-        aff = len(os.sched_getaffinity(0))
-        if aff < n:
-            n, how = aff, "sched_getaffinity"
-    except (AttributeError, OSError):
-        pass
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            with open(path) as fh:
-                parts = fh.read().split()
-            if path.endswith("cpu.max"):
-                quota, period = parts[0], float(parts[1])
-            else:
-                quota = parts[0]
-                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
-                    period = float(fh.read())
-            if quota not in ("max", "-1"):
-                q = max(1, int(float(quota) / period + 0.5))
-                if q < n:
-                    n, how = q, "cgroup cpu quota"
-            break
-        except (OSError, ValueError, IndexError):
-            continue
-    return n, how
-
-
 def cpu_baseline(P, f, profile, grid_steps, seconds):
     """The oracle's OpenMP loop (same stepper, same Philox stream) on this host's cores, on a
     bounded sample of the same workload; throughput is per path so it compares directly."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import hw_oracle
     o = hw_oracle.Oracle(profile, n_steps=grid_steps)
-    cores, how = usable_cores(o.max_threads())
+    cores, how = hw_oracle.usable_cores(o.omp_max_threads())
     t0 = time.perf_counter()
     o.zbc_moments(P, f, 1 << 13, 1, n_threads=cores)     # calibration
     rate = (1 << 13) / max(time.perf_counter() - t0, 1e-6)

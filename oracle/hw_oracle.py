@@ -52,6 +52,37 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def usable_cores(omp_max):
+    """Threads worth starting: the smallest of OpenMP's default, the affinity mask and the cgroup CPU quota
+    (a GPU box hands a job a share of the host's cores; more threads than that only get throttled)."""
+    n, how = omp_max, "omp_get_max_threads"
+    try:
+        aff = len(os.sched_getaffinity(0))
+        if aff < n:
+            n, how = aff, "sched_getaffinity"
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                parts = fh.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = parts[0], float(parts[1])
+            else:
+                quota = parts[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                    period = float(fh.read())
+            if quota not in ("max", "-1"):
+                q = max(1, int(float(quota) / period + 0.5))
+                if q < n:
+                    n, how = q, "cgroup cpu quota"
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n, how
+
+
+
 class Oracle:
     """Thin object wrapper: one model, float32 ("f32", the reference's arithmetic) or float64."""
 
@@ -80,8 +111,12 @@ class Oracle:
     def sigma(self):
         return self.m.sigma
 
-    def max_threads(self):
+    def omp_max_threads(self):
         return self.l.ora_max_threads()
+
+    def max_threads(self):
+        """Default thread count of every call below: what the job may actually use (see usable_cores)."""
+        return usable_cores(self.l.ora_max_threads())[0]
 
     def steps_to(self, S1):
         return self.l.ora_steps_to(C.byref(self.m), C.c_double(S1))
