@@ -13,6 +13,9 @@ BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --spinup-ms 200 --no-cpu-bas
 echo "rocprofv3 <--kernel-trace --stats | --pmc ...> -- $BENCH" | sed "s#$ROOT/##" > "$OUT/command.txt"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
+# the same with the steps strictly one after another on one stream: per-dispatch durations = the kernel alone on the chip
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_s1" -- $BENCH --streams 1 > "$OUT/trace_s1.log" 2>&1
+echo "trace_s1 rc=$?"
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY \
           --kernel-trace --output-format csv -d "$OUT/pmc_sq" -- $BENCH > "$OUT/pmc_sq.log" 2>&1
 echo "pmc_sq rc=$?"

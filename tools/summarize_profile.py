@@ -30,6 +30,14 @@ def main():
     stats = newest(os.path.join(src, "trace", "**", "*kernel_stats.csv"))
     if stats:
         shutil.copy(stats, os.path.join(root, "profiles", "%s_bench_kernel_stats.csv" % tag))
+    stats1 = newest(os.path.join(src, "trace_s1", "**", "*kernel_stats.csv"))
+    if stats1:
+        shutil.copy(stats1, os.path.join(root, "profiles", "%s_bench_streams1_kernel_stats.csv" % tag))
+        with open(stats1) as fh:
+            for r in csv.DictReader(fh):
+                if want in r["Name"]:
+                    out["single_stream_run"] = {"command": (out["command"] or "") + " --streams 1", "launches": int(r["Calls"]),
+                                                "avg_duration_us": float(r["AverageNs"]) / 1e3, "min_duration_us": float(r["MinNs"]) / 1e3}
     trace = newest(os.path.join(src, "trace", "**", "*kernel_trace.csv"))
     if trace:
         iv = []
