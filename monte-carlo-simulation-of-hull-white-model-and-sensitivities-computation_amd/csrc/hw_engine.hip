@@ -996,7 +996,11 @@ static int comm_run(hw_comm* cm, int64_t n_units, int count_out, double* out, fl
     NCCL_TRY(cm, cm->GroupStart());
     for (int g = 0; g < G; g++) {
         hw_ctx* c = cm->ctx[g];
-        NCCL_TRY(cm, cm->AllReduce(c->d_out, c->d_out, (size_t)count_out, ncclDouble, ncclSum, cm->comm[g], c->stream));
+        const ncclResult_t r = cm->AllReduce(c->d_out, c->d_out, (size_t)count_out, ncclDouble, ncclSum, cm->comm[g], c->stream);
+        if (r != ncclSuccess) {
+            (void)cm->GroupEnd();                                    // never leave the group open
+            return fail(HW_E_HIP, "RCCL error [ncclAllReduce, device %d]: %s", c->device, cm->GetErrorString(r));
+        }
     }
     NCCL_TRY(cm, cm->GroupEnd());
     HIP_TRY(hipSetDevice(cm->ctx[0]->device));
