@@ -1,0 +1,77 @@
+"""Property tests (hypothesis) of the host-side pieces of the path: the control-variate algebra behind beta*,
+the shard partition, the statistics of the 20-run harness and the oracle's counter-based RNG.  CPU only."""
+import math
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(min_value=4, max_value=200), st.integers(min_value=0, max_value=2 ** 32 - 1),
+       st.floats(min_value=0.1, max_value=2.0))
+def test_cv_price_is_the_regression_adjusted_mean(hwmc_mod, n, seed, P0S2):
+    """hw_cv_price on the five sums of ANY sample equals the textbook estimator (2_option:154-175): means, population
+    variance/covariance, beta = cov/varY, price = meanX - beta (meanY - P0S2); it is invariant under a shift of Y
+    together with P0S2 and scales linearly in X."""
+    rng = np.random.default_rng(seed)
+    y = rng.normal(0.9, 0.05, n)
+    x = np.maximum(0.3 * y - 0.25 + rng.normal(0, 0.01, n), 0.0)
+    sums = [x.sum(), y.sum(), (x * x).sum(), (y * y).sum(), (x * y).sum()]
+    r = hwmc_mod.cv_price(sums, n, P0S2)
+    varY = (y * y).mean() - y.mean() ** 2
+    cov = (x * y).mean() - x.mean() * y.mean()
+    assert r["mean_X"] == pytest.approx(x.mean(), rel=1e-12)
+    assert r["var_Y"] == pytest.approx(varY, rel=1e-9, abs=1e-15)
+    assert r["beta"] == pytest.approx(cov / varY, rel=1e-8, abs=1e-12)
+    assert r["price"] == pytest.approx(x.mean() - cov / varY * (y.mean() - P0S2), rel=1e-9, abs=1e-12)
+    assert -1.0 - 1e-9 <= r["rho"] <= 1.0 + 1e-9
+    x3 = 3.0 * x
+    r3 = hwmc_mod.cv_price([x3.sum(), y.sum(), (x3 * x3).sum(), (y * y).sum(), (x3 * y).sum()], n, P0S2)
+    assert r3["price"] == pytest.approx(3.0 * r["price"], rel=1e-8, abs=1e-10)
+    ys = y + 0.125
+    rs = hwmc_mod.cv_price([x.sum(), ys.sum(), (x * x).sum(), (ys * ys).sum(), (x * ys).sum()], n, P0S2 + 0.125)
+    assert rs["price"] == pytest.approx(r["price"], rel=1e-7, abs=1e-10)
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.integers(min_value=0, max_value=2 ** 45), st.integers(min_value=1, max_value=64))
+def test_shard_is_a_balanced_contiguous_partition(hwmc_mod, n, world):
+    end, sizes = 0, []
+    for rank in range(world):
+        off, cnt = hwmc_mod.parallel.shard(n, rank, world)
+        assert off == end and cnt >= 0
+        end = off + cnt
+        sizes.append(cnt)
+    assert end == n and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+@settings(max_examples=50, deadline=None)
+@given(st.lists(st.floats(min_value=0.01, max_value=1.0), min_size=20, max_size=20))
+def test_run_statistics_is_the_t_interval_of_the_reference(hwmc_mod, xs):
+    s = hwmc_mod.run_statistics(xs)
+    x = np.array(xs)
+    assert s["mean"] == pytest.approx(x.mean(), rel=1e-12)
+    assert s["sd"] == pytest.approx(x.std(ddof=1), rel=1e-9, abs=1e-15)
+    assert s["ci95_width"] == pytest.approx(2 * 2.093 * x.std(ddof=1) / math.sqrt(20), rel=1e-9, abs=1e-15)   # 2_option:318-320
+    assert s["ci_lo"] <= s["mean"] <= s["ci_hi"]
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(min_value=0, max_value=2 ** 64 - 1), st.integers(min_value=0, max_value=2 ** 64 - 1),
+       st.integers(min_value=0, max_value=2 ** 32 - 1))
+def test_oracle_philox_is_a_pure_function_of_seed_subsequence_block(oracle_mod, seed, sub, block):
+    """Counter-based: the four words of (seed, subsequence, block) do not depend on call order, differ between
+    neighbouring blocks and subsequences, and the normals built from them are finite and inside Box-Muller's range."""
+    o = oracle_mod.Oracle()
+    a = o.uint4(seed, sub, block)
+    assert a == o.uint4(seed, sub, block)
+    assert a != o.uint4(seed, sub, (block + 1) % 2 ** 32) and a != o.uint4(seed, (sub + 1) % 2 ** 64, block)
+    g = np.array(o.normal4(seed, sub, block), np.float64)
+    assert np.all(np.isfinite(g)) and np.all(np.abs(g) <= math.sqrt(2 * 32 * math.log(2)) + 1e-5)
+
+
+def test_usable_cores_never_exceeds_the_openmp_default(oracle_mod):
+    n, how = oracle_mod.usable_cores(1000)
+    assert 1 <= n <= 1000 and how in ("omp_get_max_threads", "sched_getaffinity", "cgroup cpu quota")
+    assert oracle_mod.usable_cores(1) == (1, "omp_get_max_threads")
