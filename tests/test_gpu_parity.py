@@ -431,3 +431,35 @@ def test_zcb_curve_blocked_kernel_variants(hwmc_mod, oracle_mod, monkeypatch):
     o5 = oracle_mod.Oracle("readme", n_mat=201)
     np.testing.assert_allclose(e5.simulate_zcb(2000, 4), o5.zcb_curve(2000, 4), rtol=REL_F32)
     e5.close()
+
+
+def test_full_size_properties_of_the_multi_gpu_shares(setup, hwmc_mod):
+    """One GPU's share of BASELINE configs[3] (2^24 pairs over 8 GPUs -> 2^21 per GPU) and configs[4] (2^26 pairs x
+    4000-step grid over 8 GPUs -> 2^23 per GPU, f32 vs f64): the oracle cannot follow at these sizes in seconds, so
+    the checks are size-independent properties -- shards add up to the whole, the first and the last rank's shard
+    price the same option within Monte Carlo error of the closed form, f32 and f64 steppers agree on the same draws."""
+    e, o, P, f = setup("readme")
+    n = 1 << 21
+    exact = 0.03544557                                                             # Jamshidian, readme profile
+    first = e.simulate_ZBC_control_variate(n, 4321, path_offset=0)
+    last = e.simulate_ZBC_control_variate(n, 4321, path_offset=7 * n)              # rank 7 of 8
+    halves = sum(e.simulate_ZBC_control_variate(n // 2, 4321, path_offset=7 * n + k * (n // 2)) for k in range(2))
+    np.testing.assert_allclose(last, halves, rtol=1e-13)
+    assert not np.array_equal(first, last)
+    for sums in (first, last, first + last):
+        cnt = 2 * n * (2 if sums is not first and sums is not last else 1)
+        r = hwmc_mod.cv_price(sums, cnt, float(P[-1]))
+        assert abs(r["price"] - exact) < 4 * r["ci95_halfwidth"] / 1.96
+    # stress share: 2^23 pairs on the 4000-step grid, both precisions, same seed -> same normals
+    n5 = 1 << 23
+    e32, _, P4, _ = setup("readme", "f32", 4000)
+    e64, _, _, _ = setup("readme", "f64", 4000)
+    s32 = e32.simulate_ZBC_control_variate(n5, 99, path_offset=3 * n5)
+    s64 = e64.simulate_ZBC_control_variate(n5, 99, path_offset=3 * n5)
+    np.testing.assert_allclose(s32, s64, rtol=REL_F32)
+    r32, r64 = (hwmc_mod.cv_price(s, 2 * n5, float(P4[-1])) for s in (s32, s64))
+    assert r32["price"] == pytest.approx(r64["price"], rel=REL_F32) and r32["beta"] == pytest.approx(r64["beta"], rel=REL_F32)
+    assert abs(r64["price"] - exact) < 4 * r64["ci95_halfwidth"] / 1.96 + 2e-6     # + trapezoid bias at dt = 0.0025
+    v32 = e32.simulate_sensitivity(n5, 7) / n5
+    v64 = e64.simulate_sensitivity(n5, 7) / n5
+    assert v32 == pytest.approx(v64, rel=REL_F32) and v64 == pytest.approx(0.230244, abs=1e-3)
