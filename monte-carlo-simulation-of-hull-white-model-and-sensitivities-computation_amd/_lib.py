@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhw_hip.so")
+LIB_PATH = os.environ.get("HWMC_LIB") or os.path.join(_HERE, "libhw_hip.so")   # HWMC_LIB: A/B builds (tools/)
 
 HW_OK = 0
 HW_E_INVALID, HW_E_HIP, HW_E_NO_MARKET, HW_E_NOMEM = -1, -2, -3, -4

@@ -63,6 +63,9 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
 
 // Round keys 3..10 are consumed by every block of the loop.  HWK_KEYS_IN_VGPRS=1 copies them to vector
 // registers once per thread (an SGPR operand on back-to-back v_bitop3 costs 4.1 cycles instead of 2.45).
+#ifndef HWK_CVT_AT_PRIO0
+#define HWK_CVT_AT_PRIO0 0
+#endif
 #ifndef HWK_KEYS_IN_VGPRS
 #define HWK_KEYS_IN_VGPRS 1
 #endif
@@ -208,7 +211,7 @@ __device__ __forceinline__ void pin4(uint32_t& a, uint32_t& b, uint32_t& c, uint
 // an SGPR) -- true for every wave that does not straddle a multiple of 2^32 paths.  Then word 2 after round 1,
 // hi(M0 j) ^ phi ^ k1[0], is wave-uniform as well, and the M1 multiply of round 2 runs on the scalar unit:
 // 16 vector multiplies and 18 bitwise ops per block instead of 17 and 19.
-template <bool UHI>
+template <bool UHI, bool RAISE = true>
 __device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const PhiloxPath& pp, uint32_t a2s, uint32_t j,
                                                   uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
 {
@@ -258,9 +261,11 @@ __device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const Phil
         c2 = xor3(hi0, c3, k.k1[r]);
         c3 = lo0;
     }
-    pin4(c0, c1, c2, c3);
-    HWK_SETPRIO(1);
-    pin4(c0, c1, c2, c3);
+    if constexpr (RAISE) {
+        pin4(c0, c1, c2, c3);
+        HWK_SETPRIO(1);
+        pin4(c0, c1, c2, c3);
+    }
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
 __device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const PhiloxPath& pp, uint32_t j,
@@ -534,10 +539,26 @@ __device__ __forceinline__ void ou_walk(const PhiloxKey& key, const PhiloxPath (
 #pragma unroll
                 for (int q = 0; q < ILP; q++) {
                     uint32_t w0, w1, w2, w3;
-                    philox_block_prio<UHI>(key, pp[q], a2s[q], (uint32_t)j, w0, w1, w2, w3);
                     float s0, sn0, cs0, s1, sn1, cs1;
+#if HWK_CVT_AT_PRIO0
+                    philox_block_prio<UHI, false>(key, pp[q], a2s[q], (uint32_t)j, w0, w1, w2, w3);
+                    constexpr float kInv = 2.3283064e-10f;
+                    float u0 = __builtin_fmaf((float)w0, kInv, kInv), v0 = __builtin_fmaf((float)w1, kInv, kInv);
+                    float u1 = __builtin_fmaf((float)w2, kInv, kInv), v1 = __builtin_fmaf((float)w3, kInv, kInv);
+                    asm volatile("" : "+v"(u0), "+v"(v0), "+v"(u1), "+v"(v1));
+                    HWK_SETPRIO(1);
+                    asm volatile("" : "+v"(u0), "+v"(v0), "+v"(u1), "+v"(v1));
+                    s0 = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u0));
+                    sn0 = __builtin_amdgcn_sinf(v0);
+                    cs0 = __builtin_amdgcn_cosf(v0);
+                    s1 = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u1));
+                    sn1 = __builtin_amdgcn_sinf(v1);
+                    cs1 = __builtin_amdgcn_cosf(v1);
+#else
+                    philox_block_prio<UHI>(key, pp[q], a2s[q], (uint32_t)j, w0, w1, w2, w3);
                     box_muller_parts(w0, w1, s0, sn0, cs0);
                     box_muller_parts(w2, w3, s1, sn1, cs1);
+#endif
                     const float a0 = __builtin_fmaf(e, sn0, cs0), a1 = __builtin_fmaf(e, sn1, cs1);
                     const float b0 = sn0 + cs0, b1 = sn1 + cs1;
                     const float t = __builtin_fmaf(e2, y[q], s0 * a0);
