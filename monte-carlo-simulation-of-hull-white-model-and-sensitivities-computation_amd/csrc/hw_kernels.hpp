@@ -197,6 +197,19 @@ __device__ __forceinline__ void normal4(const PhiloxKey& k, const PhiloxPath& pp
         __builtin_amdgcn_sched_barrier(0);    \
     } while (0)
 
+// the toggles INSIDE the Philox rounds (experiments: -DHWK_PRIO_ROUNDS=0 keeps only the block-level phases,
+// -DHWK_PRIO_ROUNDS=2 uses priorities 0/2/3 instead of 0/1)
+#ifndef HWK_PRIO_ROUNDS
+#define HWK_PRIO_ROUNDS 1
+#endif
+#if HWK_PRIO_ROUNDS == 1
+#define HWK_SETPRIO_R(n) HWK_SETPRIO(n)
+#elif HWK_PRIO_ROUNDS == 2
+#define HWK_SETPRIO_R(n) HWK_SETPRIO((n) ? 2 : 0)
+#else
+#define HWK_SETPRIO_R(n) do { } while (0)
+#endif
+
 __device__ __forceinline__ void pin2(uint32_t& a, uint32_t& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void pin4(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d)
 {
@@ -249,12 +262,12 @@ __device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const Phil
 #pragma unroll
     for (int r = 3; r < 10; r++) {                  // rounds 4..10: multiplies at priority 1, xors at 0
         pin2(c0, c2);
-        HWK_SETPRIO(1);
+        HWK_SETPRIO_R(1);
         pin2(c0, c2);
         mulhilo(kM0, c0, hi0, lo0);
         mulhilo(kM1, c2, hi1, lo1);
         pin2(hi0, hi1);
-        HWK_SETPRIO(0);
+        HWK_SETPRIO_R(0);
         pin2(hi0, hi1);
         c0 = xor3(hi1, c1, k.k0[r]);
         c1 = lo1;
