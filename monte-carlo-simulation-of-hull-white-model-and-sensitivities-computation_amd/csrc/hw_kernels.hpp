@@ -26,10 +26,11 @@ constexpr int kMaxScen = 3;
 
 // ------------------------------------------------------------------------------------------
 // Philox4x32-10, rocRAND counter layout: counter = {block j, 0, path lo, path hi}, key = seed.
-// The ten round keys depend only on the seed (wave-uniform -> SGPRs).  Because counter words
-// 0/1 are wave-uniform and words 2/3 are constant along a path, round 1 and half of rounds 2-3
-// are loop-invariant per lane: philox_path() hoists them, philox_block() spends 17 wide
-// multiplies and 34 xors per block instead of 20 and 40.
+// The ten round keys depend only on the seed (wave-uniform).  Because counter words 0/1 are
+// wave-uniform and words 2/3 are constant along a path, round 1 and half of rounds 2-3 are
+// loop-invariant per lane: philox_path() hoists them, philox_block() spends 17 wide multiplies
+// (16 in philox_block_prio<UHI = true>) and 19 bitwise ops (v_bitop3_b32 = 3-input xor) per block
+// instead of rocRAND's 20 and 40.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kM0 = 0xD2511F53u, kM1 = 0xCD9E8D57u, kW0 = 0x9E3779B9u, kW1 = 0xBB67AE85u;
 
