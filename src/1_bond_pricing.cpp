@@ -28,7 +28,7 @@ int main(int argc, char** argv)
     printf("Running Monte Carlo simulation...\n");
     std::vector<double> P_sum;
     float sim_ms = 0.0f;
-    fleet.zcb(n, seed, 0.0, &P_sum, &sim_ms);                                       // warm-up launch
+    fleet.warm(opt.spinup_ms, [&] { fleet.zcb(n, seed, 0.0, &P_sum, &sim_ms); });   // warm-up launches
     fleet.zcb(n, seed, 0.0, &P_sum, &sim_ms);
     printf("Simulation complete\n");
 

@@ -48,7 +48,7 @@ static double price_once(app::Fleet& fleet, const app::Options& opt, int64_t n, 
     double sums[5];
     float ms = 0.0f;
     hw_zbc_request r = option_request(opt, n, seed);
-    fleet.zbc(r, sums, &ms);                                                    // warm-up launch
+    fleet.warm(opt.spinup_ms, [&] { fleet.zbc(r, sums, &ms); });                // warm-up launches
     fleet.zbc(r, sums, &ms);
     const app::CvResult c = app::cv_price(sums, 2 * n, P0S2);
     printf("=== RESULTS===\n");

@@ -83,7 +83,7 @@ int main(int argc, char** argv)
     printf("  Option: ZBC(S1=%.1f, S2=%.1f, K=e^-0.1)\n  Paths:  %lld Monte Carlo simulations\n", kS1, kS2, (long long)n);
     kernel_report(fleet);
     float ms = 0.0f;
-    fleet.vega(n, seed, kS1, kS2, K, &ms);                                       // warm-up launch
+    fleet.warm(opt.spinup_ms, [&] { fleet.vega(n, seed, kS1, kS2, K, &ms); });   // warm-up launches
     const double sens_mc = fleet.vega(n, seed, kS1, kS2, K, &ms) / (double)n;    // 3_sens:261
     printf("Performance Results\nVega:   %.6f\nComputation:      %.2f ms\nThroughput:       %.2f M paths/sec\n", sens_mc, ms, (n / ms) / 1000.0);
 

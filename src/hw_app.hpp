@@ -19,6 +19,7 @@
 #pragma once
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -44,6 +45,7 @@ struct Options {
     int stepper = HW_STEPPER_SUPERPOSED;
     std::string market = "mc";
     int gpus = 1, device = 0;
+    int spinup_ms = 150;   // untimed repeats of the first launch before the timed one: the chip's clock ramps over ~100 ms of load
     int reduce = -1;   // cross-device sum: -1 automatic (RCCL when --gpus > 1), 0 host threads, 1 RCCL all-reduce
     int answer = -1;   // -1 ask on stdin, 0 no, 1 yes
     int64_t n() const { return (int64_t)1 << paths_log2; }
@@ -75,6 +77,7 @@ inline Options parse(int argc, char** argv)
         else if (a == "--gpus") o.gpus = atoi(val());
         else if (a == "--device") o.device = atoi(val());
         else if (a == "--reduce") o.reduce = !strcmp(val(), "rccl") ? 1 : 0;
+        else if (a == "--spinup-ms") o.spinup_ms = atoi(val());
         else if (a == "--yes") o.answer = 1;
         else if (a == "--no") o.answer = 0;
         else { fprintf(stderr, "unknown flag %s (see src/hw_app.hpp)\n", a.c_str()); exit(2); }
@@ -222,6 +225,14 @@ struct Fleet {
     }
     void set_market(const float* P, const float* f) { for (hw_ctx* c : ctx) HW_CHECK(hw_set_market(c, P, f, p.n_mat)); }
     void destroy() { hw_comm_destroy(comm); comm = nullptr; for (hw_ctx* c : ctx) hw_destroy(c); ctx.clear(); }
+    // Warm-up: at least one call of fn, repeated until `ms` of wall time have passed.  The reference times a single
+    // cold launch (2_option:131-144); a cold MI355X runs the first ~100 ms of work 10-15 % below its sustained clock.
+    template <typename F>
+    void warm(int ms, F fn)
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        do { fn(); } while (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() < ms);
+    }
     // shard [0, n) over the devices; returns {offset, count} of device g
     void shard(int64_t n, int g, int64_t* off, int64_t* cnt) const
     {
