@@ -42,15 +42,22 @@ run-q3: q3
 	@mkdir -p data plots
 	./$(BIN)/q3 $(ARGS)
 
-benchmark:
-	@mkdir -p tools/bin data plots
+# the reference's optional reduction-strategy benchmark (src/benchmark_reductions.cu), re-done for gfx950;
+# `make microbench` builds the instruction-issue microbenchmarks under tools/
+benchmark: $(SRC)/benchmark_reductions.hip $(LIB)
+	@mkdir -p $(BIN) data plots
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -I include $< -o $(BIN)/$@ $(LDFLAGS)
+
+run-benchmark: benchmark
+	@mkdir -p data plots
+	./$(BIN)/benchmark $(ARGS)
+
+microbench:
+	@mkdir -p tools/bin
 	$(HIPCC) --offload-arch=gfx950 -O3 tools/valu_rates.hip -o tools/bin/valu_rates
 	$(HIPCC) --offload-arch=gfx950 -O3 tools/valu_patterns.hip -o tools/bin/valu_patterns
+	$(HIPCC) --offload-arch=gfx950 -O3 tools/coissue_probe.hip -o tools/bin/coissue_probe
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -I $(PKG)/csrc tools/loop_lab.hip -o tools/bin/loop_lab
-
-run-benchmark: benchmark lib
-	@mkdir -p data plots
-	python3 tools/benchmark_reductions.py
 
 run-all: run-q1 run-q2 run-q3
 
@@ -66,4 +73,4 @@ clean:
 clean-all:
 	rm -rf $(BIN) data plots
 
-.PHONY: all lib oracle benchmark run-benchmark clean clean-all run-q1 run-q2 run-q3 run-all analyze
+.PHONY: all lib oracle benchmark run-benchmark microbench clean clean-all run-q1 run-q2 run-q3 run-all analyze

@@ -21,7 +21,7 @@ def _run(exe, cwd, *args, stdin=None, check=True):
 
 @pytest.fixture(scope="module")
 def built():
-    subprocess.check_call(["make", "-C", ROOT, "all"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", ROOT, "all", "benchmark"], stdout=subprocess.DEVNULL)
 
 
 def test_q2_without_q1_exits_like_the_reference(built, tmp_path):
@@ -100,3 +100,20 @@ def test_rccl_reduce_flag_gives_the_same_files(built, tmp_path):
     _run("q3", a, *common, "--no")
     r3 = _run("q3", b, *common, "--reduce", "rccl", "--no")
     assert "ERROR" not in r3.stdout
+
+
+def test_reduction_benchmark_target(built, tmp_path):
+    """bin/benchmark (the reference's optional `make benchmark`, src/benchmark_reductions.cu): needs q1's curves, runs
+    the production path loop with five ways of finishing the sums, all of which must give the same price, and writes
+    data/benchmark_reductions.json in the schema the reference's analyze.py reads (analyze.py:195-203)."""
+    r = _run("benchmark", tmp_path, check=False)
+    assert r.returncode == 1 and "Did you run Q1 first?" in r.stdout
+    _run("q1", tmp_path, "--paths-log2", "16", "--seed", "5", "--theta-profile", "readme", "--spinup-ms", "0")
+    r = _run("benchmark", tmp_path, "--paths-log2", "18", "--theta-profile", "readme")
+    assert "All methods produce identical results" in r.stdout
+    j = json.load(open(tmp_path / "data" / "benchmark_reductions.json"))
+    assert j["parameters"]["N_PATHS"] == 1 << 18 and len(j["results"]) == 5
+    prices = {x["price"] for x in j["results"]}
+    assert len(prices) == 1 and abs(prices.pop() - 0.0354) < 2e-3
+    for x in j["results"]:
+        assert set(x) == {"method", "time_ms", "throughput_Mpaths_per_sec", "price"} and x["time_ms"] > 0
