@@ -164,6 +164,13 @@ int  hw_vega_pathwise_async(hw_ctx* ctx, int64_t n_paths, uint64_t seed, uint64_
                             double S1, double S2, double K, int32_t antithetic,
                             double* d_out, void* stream);
 
+/* n_runs independent Vega estimates in ONE launch: run k uses seed + k*seed_stride on the same paths.  Replaces
+ * the 20 init_rng / launch / D2H cycles of the Vega bootstrap (src/3_sensitivity_analysis.cu:527-654, seeds
+ * base + run*982451653 at :545); out[n_runs].  Each run's sum is bit-identical to a separate hw_vega_pathwise call. */
+int  hw_vega_pathwise_runs(hw_ctx* ctx, int64_t n_paths, uint64_t seed, uint64_t path_offset, double S1, double S2,
+                           double K, int32_t antithetic, int32_t n_runs, uint64_t seed_stride, double* out,
+                           float* kernel_ms);
+
 /* Replaces simulate_paths_show (market_data.cuh:136-160): out[n][n_steps+1] float32 row-major. */
 int  hw_sample_paths(hw_ctx* ctx, int32_t n, uint64_t seed, uint64_t path_offset, float* out);
 

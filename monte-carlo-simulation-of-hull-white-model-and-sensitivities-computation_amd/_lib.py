@@ -68,6 +68,8 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p]),
     "hw_vega_pathwise": (C.c_int, [_CTX, C.c_int64, C.c_uint64, C.c_uint64, C.c_double,
                                    C.c_double, C.c_double, C.c_int32, _DP, _FP]),
+    "hw_vega_pathwise_runs": (C.c_int, [_CTX, C.c_int64, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_double,
+                                        C.c_int32, C.c_int32, C.c_uint64, _DP, C.POINTER(C.c_float)]),
     "hw_vega_pathwise_async": (C.c_int, [_CTX, C.c_int64, C.c_uint64, C.c_uint64, C.c_double,
                                          C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p]),
     "hw_sample_paths": (C.c_int, [_CTX, C.c_int32, C.c_uint64, C.c_uint64, _FP]),

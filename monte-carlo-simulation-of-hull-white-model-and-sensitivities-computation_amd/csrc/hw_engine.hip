@@ -379,7 +379,8 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
 
 template <typename REAL>
 int launch_vega(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset, double S1, double S2,
-                double K, int antithetic, int n_steps_S1, double* d_out, hipStream_t st)
+                double K, int antithetic, int n_steps_S1, double* d_out, hipStream_t st, int n_runs = 1,
+                uint64_t seed_stride = 0)
 {
     const hw_params& p = c->p;
     Scenario s;
@@ -391,9 +392,13 @@ int launch_vega(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset,
 
     const int ilp = c->ilp;
     const Geometry g = geometry(c, n_paths, ilp);
-    rc = ensure_partials(c, (size_t)g.grid);
+    if ((int64_t)g.grid * n_runs > ((int64_t)1 << 22)) return fail(HW_E_INVALID, "n_runs x workgroups per run exceeds 2^22");
+    const int total_grid = g.grid * n_runs;
+    rc = ensure_partials(c, (size_t)total_grid);
     if (rc) return rc;
     hwk::VegaArgs<REAL> a{};
+    a.blocks_per_run = (uint32_t)g.grid;
+    a.seed_stride = seed_stride;
     a.n_paths = n_paths;
     a.seed = seed;
     a.path_offset = path_offset;
@@ -409,15 +414,15 @@ int launch_vega(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset,
     a.cD = (REAL)cD[n_steps_S1];
     a.s_over_sigma = (REAL)(s.k.sig_st / p.sigma * hwk::kBmScale);
     a.zs = (REAL)(s.k.dt * s.k.sig_st / p.sigma * hwk::kBmScale);
-    unsigned* tk = c->single_launch ? c->d_ticket : nullptr;
+    unsigned* tk = (c->single_launch && n_runs == 1) ? c->d_ticket : nullptr;
     prof_mark(c, st, 0);
     if (ilp == 2)
-        hipLaunchKernelGGL((hwk::vega_pathwise_kernel<REAL, 2>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials, tk, d_out);
+        hipLaunchKernelGGL((hwk::vega_pathwise_kernel<REAL, 2>), dim3(total_grid), dim3(g.block), 0, st, a, c->d_partials, tk, d_out);
     else
-        hipLaunchKernelGGL((hwk::vega_pathwise_kernel<REAL, 1>), dim3(g.grid), dim3(g.block), 0, st, a, c->d_partials, tk, d_out);
+        hipLaunchKernelGGL((hwk::vega_pathwise_kernel<REAL, 1>), dim3(total_grid), dim3(g.block), 0, st, a, c->d_partials, tk, d_out);
     prof_mark(c, st, 1);
     HIP_TRY(hipGetLastError());
-    return finish_columns(c, st, g.grid, 1, d_out);
+    return finish_columns(c, st, g.grid, 1, d_out, n_runs);
 }
 
 // run `enqueue(d_out, stream)` on the context stream between events, copy n doubles back
@@ -683,6 +688,23 @@ int hw_vega_pathwise(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_of
     if (!c || !out) return fail(HW_E_INVALID, "null argument");
     return timed_sync(c, 1, out, kernel_ms, [&](double* d_out, hipStream_t st) {
         return vega_enqueue(c, n_paths, seed, path_offset, S1, S2, K, antithetic, d_out, st);
+    });
+}
+
+int hw_vega_pathwise_runs(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset, double S1, double S2,
+                          double K, int32_t antithetic, int32_t n_runs, uint64_t seed_stride, double* out, float* kernel_ms)
+{
+    if (!c || !out) return fail(HW_E_INVALID, "null argument");
+    if (n_runs < 1 || n_runs > kOutCap) return fail(HW_E_INVALID, "n_runs must be 1..%d", kOutCap);
+    hw_zbc_request r{};
+    r.n_pairs = n_paths; r.S1 = S1; r.S2 = S2; r.K = K;
+    int n_steps_S1 = 0;
+    int rc = check_request(c, &r, &n_steps_S1);
+    if (rc) return rc;
+    return timed_sync(c, n_runs, out, kernel_ms, [&](double* d_out, hipStream_t st) {
+        return c->p.precision == HW_F64
+                   ? launch_vega<double>(c, n_paths, seed, path_offset, S1, S2, K, antithetic, n_steps_S1, d_out, st, n_runs, seed_stride)
+                   : launch_vega<float>(c, n_paths, seed, path_offset, S1, S2, K, antithetic, n_steps_S1, d_out, st, n_runs, seed_stride);
     });
 }
 

@@ -994,6 +994,10 @@ struct VegaArgs {
     REAL cD;                  // mean of int d_sigma r
     REAL s_over_sigma;        // s / sigma
     REAL zs;                  // dt * s / sigma : stochastic part of int d_sigma r = zs (S - y/2)
+    // several independent runs in one launch (the 20-run Vega bootstrap, 3_sens:527-654): workgroup b belongs to
+    // run b / blocks_per_run and uses seed + run * seed_stride.  One run: blocks_per_run = gridDim.x.
+    uint32_t blocks_per_run;
+    uint64_t seed_stride;
 };
 
 template <typename REAL>
@@ -1016,11 +1020,13 @@ vega_pathwise_kernel(const VegaArgs<REAL> a, double* __restrict__ partials,
                      unsigned* __restrict__ ticket, double* __restrict__ out)
 {
     __shared__ double smem[kMaxWaves];
-    const PhiloxKey key = philox_key(a.seed);
+    const uint32_t run = blockIdx.x / a.blocks_per_run;
+    const uint32_t block_in_run = blockIdx.x - run * a.blocks_per_run;
+    const PhiloxKey key = philox_key(a.seed + (uint64_t)run * a.seed_stride);
     PhiloxKey vkey = key;                           // round keys 3..10 in vector registers for the loop
     philox_key_to_vgprs(vkey);
-    const int64_t T = (int64_t)gridDim.x * blockDim.x;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t T = (int64_t)a.blocks_per_run * blockDim.x;
+    const int64_t t = (int64_t)block_in_run * blockDim.x + threadIdx.x;
     double acc[1] = {0.0};
     for (int it = 0; it < a.iters; it++) {
         PhiloxPath pp[ILP];

@@ -235,6 +235,17 @@ class HullWhiteEngine:
                                           1 if antithetic else 0, _dp(out), C.byref(ms)))
         return (float(out[0]), ms.value) if return_ms else float(out[0])
 
+    def simulate_sensitivity_runs(self, n_paths, seed, n_runs=20, seed_stride=982451653, path_offset=0, S1=5.0,
+                                  S2=10.0, K=None, antithetic=False, return_ms=False):
+        """n_runs Vega sums in one launch (the bootstrap of 3_sens:527-654): float64[n_runs]."""
+        out = np.zeros(n_runs, np.float64)
+        ms = C.c_float(0)
+        L.check(self.lib.hw_vega_pathwise_runs(self._ctx, int(n_paths), int(seed), int(path_offset), float(S1),
+                                               float(S2), float(K_DEFAULT if K is None else K),
+                                               int(bool(antithetic)), int(n_runs), int(seed_stride), _dp(out),
+                                               C.byref(ms)))
+        return (out, ms.value) if return_ms else out
+
     def enqueue_sensitivity(self, d_out_ptr, n_paths, seed, path_offset=0, S1=5.0, S2=10.0, K=None,
                             antithetic=False, stream=None):
         L.check(self.lib.hw_vega_pathwise_async(

@@ -140,9 +140,15 @@ int main(int argc, char** argv)
         std::vector<double> v(runs);
         const uint64_t base = opt.have_seed ? opt.seed + 1000003ull : t0 * 2ull;  // 3_sens:539
         printf("Running %d independent Monte Carlo simulations...\n", runs);
-        for (int k = 0; k < runs; k++) {
-            v[k] = fleet.vega(n, base + (uint64_t)k * 982451653ull, kS1, kS2, K, nullptr) / (double)n;   // 3_sens:545
-            if ((k + 1) % 5 == 0) printf("  Completed %d/%d runs...\n", k + 1, runs);
+        if (fleet.ctx.size() == 1) {                 // all 20 runs in ONE launch, each bit-identical to its own launch
+            HW_CHECK(hw_vega_pathwise_runs(fleet.ctx[0], n, base, 0, kS1, kS2, K, 0, runs, 982451653ull, v.data(), nullptr));   // 3_sens:545
+            for (int k = 0; k < runs; k++) v[k] /= (double)n;
+            printf("  Completed %d/%d runs (one launch)...\n", runs, runs);
+        } else {
+            for (int k = 0; k < runs; k++) {
+                v[k] = fleet.vega(n, base + (uint64_t)k * 982451653ull, kS1, kS2, K, nullptr) / (double)n;   // 3_sens:545
+                if ((k + 1) % 5 == 0) printf("  Completed %d/%d runs...\n", k + 1, runs);
+            }
         }
         const app::RunStats s = app::run_stats(v);
         printf("\nSTATISTICAL VALIDATION RESULTS\n\nSample Statistics (N = %d runs):\n", runs);

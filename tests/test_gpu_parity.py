@@ -285,6 +285,19 @@ def test_vega_pathwise_vs_oracle(setup, golden, precision):
     assert a != b and abs(a / 8192 - b / 4096) < 0.02
 
 
+def test_vega_batched_runs_equal_separate_launches(setup):
+    """The 20-run Vega bootstrap in one launch (hw_vega_pathwise_runs, 3_sens:527-654): every run bit-identical
+    to its own launch, f32 and f64, ragged count and an offset."""
+    for prec in ("f32", "f64"):
+        e, o, P, f = setup("readme", prec)
+        runs = e.simulate_sensitivity_runs(3001, 77, n_runs=20, seed_stride=982451653, path_offset=500)
+        for k in (0, 1, 7, 19):
+            assert runs[k] == e.simulate_sensitivity(3001, 77 + k * 982451653, path_offset=500)
+        assert len(set(runs.tolist())) == 20
+    anti = e.simulate_sensitivity_runs(1000, 5, n_runs=3, seed_stride=11, antithetic=True)
+    assert anti[2] == e.simulate_sensitivity(1000, 5 + 22, antithetic=True)
+
+
 def test_finite_difference_vega(setup, hwmc_mod, golden):
     e, o, P, f = setup("head")
     n, seed, eps = 1 << 14, 1234, 1e-3
