@@ -50,6 +50,19 @@ constexpr double kLog2e = 1.4426950408889634074;
 
 }  // namespace
 
+// host-side constants of one (sigma, drift table, option) combination: see build_scenario()
+struct Scenario {
+    double sigma;
+    int drift_mode;
+    hw::StepConstants k;
+    std::vector<double> drift;
+    double m_n, cI_n;   // mean short rate and mean integral at S1
+    double A, B;
+    // cache key (the inputs build_scenario() was called with)
+    double key_sigma, key_S1, key_S2;
+    int key_drift_mode, key_steps;
+};
+
 struct hw_ctx {
     hw_params p{};
     int device = 0;
@@ -73,6 +86,11 @@ struct hw_ctx {
     int ilp = 1;
     int single_launch = 0;            // 0: path kernel + column pass; 1: in-kernel sharded-ticket finish
     int curve_generic = 0;            // env HWMC_CURVE_GENERIC=1: always run the per-step curve kernel (A/B tests)
+    // the last few scenarios built (tables + mean path + A, B cost ~8 us of host time per pricing call otherwise);
+    // emptied by hw_set_market
+    std::vector<Scenario> scen_cache;
+    int vega_key_steps = -1;          // mean of d_sigma r and of its integral at S1 (depend on the parameters only)
+    double vega_Dn = 0.0, vega_cDn = 0.0;
     // optional per-launch event pairs around the path kernel (hw_profile_enable)
     std::vector<hipEvent_t> prof_ev;
     int prof_used = 0, prof_cap = 0;
@@ -146,21 +164,18 @@ int finish_columns(hw_ctx* c, hipStream_t st, int rows, int ncol, double* d_out,
     return HW_OK;
 }
 
-struct Scenario {
-    double sigma;
-    int drift_mode;
-    hw::StepConstants k;
-    std::vector<double> drift;
-    double m_n, cI_n;   // mean short rate and mean integral at S1
-    double A, B;
-};
-
 int build_scenario(hw_ctx* c, double sigma, int drift_mode, int n_steps_S1, double S1, double S2,
                    Scenario* s)
 {
     if (!(sigma > 0.0)) sigma = c->p.sigma;
     if (drift_mode != HW_DRIFT_BASE && drift_mode != HW_DRIFT_SHIFTED)
         return fail(HW_E_INVALID, "drift_mode must be HW_DRIFT_BASE or HW_DRIFT_SHIFTED");
+    for (const Scenario& q : c->scen_cache)
+        if (q.key_sigma == sigma && q.key_drift_mode == drift_mode && q.key_steps == n_steps_S1 && q.key_S1 == S1 && q.key_S2 == S2) {
+            *s = q;
+            return HW_OK;
+        }
+    s->key_sigma = sigma; s->key_drift_mode = drift_mode; s->key_steps = n_steps_S1; s->key_S1 = S1; s->key_S2 = S2;
     s->sigma = sigma;
     s->drift_mode = drift_mode;
     s->k = hw::step_constants(c->p, sigma);
@@ -173,6 +188,8 @@ int build_scenario(hw_ctx* c, double sigma, int drift_mode, int n_steps_S1, doub
     s->m_n = m[n_steps_S1];
     s->cI_n = cI[n_steps_S1];
     hw::bond_AB(c->p, sigma, c->P, c->f, S1, S2, &s->A, &s->B);
+    if (c->scen_cache.size() >= 6) c->scen_cache.erase(c->scen_cache.begin());
+    c->scen_cache.push_back(*s);
     return HW_OK;
 }
 
@@ -386,9 +403,14 @@ int launch_vega(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset,
     Scenario s;
     int rc = build_scenario(c, p.sigma, HW_DRIFT_BASE, n_steps_S1, S1, S2, &s);
     if (rc) return rc;
-    std::vector<double> sdrift, D, cD;
-    hw::drift_tables(p, p.sigma, nullptr, &sdrift);
-    hw::mean_path(0.0, s.k.e, s.k.dt, sdrift, n_steps_S1, &D, &cD);       // 3_sens:41,44,58-61
+    if (c->vega_key_steps != n_steps_S1) {
+        std::vector<double> sdrift, D, cD;
+        hw::drift_tables(p, p.sigma, nullptr, &sdrift);
+        hw::mean_path(0.0, s.k.e, s.k.dt, sdrift, n_steps_S1, &D, &cD);   // 3_sens:41,44,58-61
+        c->vega_Dn = D[n_steps_S1];
+        c->vega_cDn = cD[n_steps_S1];
+        c->vega_key_steps = n_steps_S1;
+    }
 
     const int ilp = c->ilp;
     const Geometry g = geometry(c, n_paths, ilp);
@@ -410,8 +432,8 @@ int launch_vega(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset,
     a.cz = z.cz; a.cw = z.cw; a.D0 = z.D0; a.P0 = z.P0; a.K = z.K;
     a.B = (REAL)s.B;
     a.gB = (REAL)(p.sigma / (2.0 * p.a) * (-std::expm1(-2.0 * p.a * S1)) * s.B);
-    a.Dn = (REAL)D[n_steps_S1];
-    a.cD = (REAL)cD[n_steps_S1];
+    a.Dn = (REAL)c->vega_Dn;
+    a.cD = (REAL)c->vega_cDn;
     a.s_over_sigma = (REAL)(s.k.sig_st / p.sigma * hwk::kBmScale);
     a.zs = (REAL)(s.k.dt * s.k.sig_st / p.sigma * hwk::kBmScale);
     unsigned* tk = (c->single_launch && n_runs == 1) ? c->d_ticket : nullptr;
@@ -575,6 +597,7 @@ int hw_set_market(hw_ctx* c, const float* P, const float* f, int32_t n_mat)
             return fail(HW_E_INVALID, "market curve has a non-positive or non-finite entry at %d", i);
     c->P.assign(P, P + n_mat);
     c->f.assign(f, f + n_mat);
+    c->scen_cache.clear();
     c->have_market = true;
     return HW_OK;
 }
