@@ -356,7 +356,7 @@ def main():
             with open(pmc) as fh:
                 traffic = json.load(fh)["hbm_traffic_bytes_per_launch"]["corrected_bytes"]
             traffic_src = "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH_SIZE x2 on gfx950)"
-        vm = VALU_MODEL[a.stepper]
+        vm = VALU_MODEL["superposed_f64" if (a.stepper == "superposed" and a.precision == "f64") else a.stepper]
         cyc_per_block = 2 * vm["full"] + 4 * vm["half"] + 8 * vm["quarter"]
         waves = (n_pairs + 63) // 64
         simd_cycles = waves * (steps_exec / 4.0) * cyc_per_block
