@@ -521,11 +521,20 @@ __global__ void finalize_columns_kernel(const double* __restrict__ partials, int
 // block on y instead of four.  1 - e is exact in float (Sterbenz), and the rounding of W - e y, divided by
 // 1 - e ~ 1e-2..2.5e-3, stays at ~2e-6 of S: the same size as the rounding of 500..2000 sequential adds.
 // ------------------------------------------------------------------------------------------
+#ifndef HWK_ANGLE_BITS
+#define HWK_ANGLE_BITS 0
+#endif
 __device__ __forceinline__ void box_muller_parts(uint32_t x, uint32_t y, float& s, float& sn, float& cs)
 {
     constexpr float kInv = 2.3283064e-10f;
     const float u = __builtin_fmaf((float)x, kInv, kInv);
+#if HWK_ANGLE_BITS
+    // experiment: the angle in revolutions as 1 + (top 23 bits of y) 2^-23 in [1, 2), one v_alignbit_b32 instead of
+    // v_cvt_f32_u32 + v_fmamk_f32; v_sin/v_cos are periodic in whole revolutions
+    const float w = __builtin_bit_cast(float, __builtin_amdgcn_alignbit(0x7Fu, y, 9u));
+#else
     const float w = __builtin_fmaf((float)y, kInv, kInv);
+#endif
     s = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u));
     sn = __builtin_amdgcn_sinf(w);
     cs = __builtin_amdgcn_cosf(w);
