@@ -11,8 +11,8 @@
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 constexpr int kChains = 8, kUnroll = 4;
-enum Op { NONE = 0, XOR, FMA, MAD64, CVT, SIN, LOG, SQRT, BITOP3, NOPS };
-const char* kNames[] = {"none", "v_xor", "v_fma", "v_mad_u64", "v_cvt", "v_sin", "v_log", "v_sqrt", "v_bitop3"};
+enum Op { NONE = 0, XOR, FMA, MAD64, CVT, SIN, LOG, SQRT, BITOP3, PKFMA, F64FMA, NOPS };
+const char* kNames[] = {"none", "v_xor", "v_fma", "v_mad_u64", "v_cvt", "v_sin", "v_log", "v_sqrt", "v_bitop3", "v_pk_fma", "v_fma_f64"};
 
 template <int OP>
 __device__ __forceinline__ void stream(int iters, unsigned seed, unsigned& acc)
@@ -20,9 +20,12 @@ __device__ __forceinline__ void stream(int iters, unsigned seed, unsigned& acc)
     if (OP == NONE) return;
     unsigned v[kChains];
     float f[kChains];
+    double d2[kChains];
     unsigned k1 = 0xD2511F53u, k2 = 0x9E3779B9u;
     float c1 = 1.0000001f, c2 = 1e-9f;
-    for (int c = 0; c < kChains; c++) { v[c] = threadIdx.x * 2654435761u + c + seed; f[c] = 0.3f + 0.01f * (float)((threadIdx.x + c + seed) & 15); }
+    for (int c = 0; c < kChains; c++) { v[c] = threadIdx.x * 2654435761u + c + seed; f[c] = 0.3f + 0.01f * (float)((threadIdx.x + c + seed) & 15); d2[c] = (double)f[c]; }
+    double dk1 = 1.0000000001, dk2 = 1e-12;
+    asm volatile("" : "+v"(dk1), "+v"(dk2));
     asm volatile("" : "+v"(k1), "+v"(k2), "+v"(c1), "+v"(c2));
     for (int i = 0; i < iters; i++) {
 #pragma unroll
@@ -34,13 +37,15 @@ __device__ __forceinline__ void stream(int iters, unsigned seed, unsigned& acc)
                 if (OP == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[c]) : "v"(c1), "v"(c2));
                 if (OP == MAD64) { unsigned long long d; asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(v[c]), "v"(k1) : "vcc"); v[c] = (unsigned)(d >> 32); }
                 if (OP == CVT) asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(f[c]) : "v"(v[c]));
+                if (OP == PKFMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(d2[c]) : "v"(dk1), "v"(dk2));
+                if (OP == F64FMA) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d2[c]) : "v"(dk1), "v"(dk2));
                 if (OP == SIN) asm volatile("v_sin_f32 %0, %0" : "+v"(f[c]));
                 if (OP == LOG) asm volatile("v_log_f32 %0, %0" : "+v"(f[c]));
                 if (OP == SQRT) asm volatile("v_sqrt_f32 %0, %0" : "+v"(f[c]));
             }
         }
     }
-    for (int c = 0; c < kChains; c++) acc += v[c] + __float_as_uint(f[c]);
+    for (int c = 0; c < kChains; c++) acc += v[c] + __float_as_uint(f[c]) + (unsigned)__double_as_longlong(d2[c]);
 }
 
 template <int A, int B>
@@ -85,6 +90,7 @@ int main(int argc, char** argv)
 #define ROW(A, B) {kNames[A], kNames[B], get<A, B>(), get<A, NONE>(), get<NONE, B>()}
     Row rows[] = {
         ROW(XOR, XOR), ROW(XOR, FMA), ROW(XOR, MAD64), ROW(XOR, CVT), ROW(XOR, SIN), ROW(BITOP3, SIN), ROW(FMA, SIN),
+        ROW(XOR, PKFMA), ROW(PKFMA, PKFMA), ROW(MAD64, PKFMA), ROW(CVT, PKFMA), ROW(SIN, PKFMA), ROW(XOR, F64FMA), ROW(CVT, CVT),
         ROW(MAD64, MAD64), ROW(MAD64, CVT), ROW(MAD64, SIN), ROW(MAD64, LOG), ROW(CVT, SIN), ROW(SIN, SIN), ROW(SIN, LOG), ROW(SIN, SQRT),
     };
     const double instr = (double)iters * kChains * kUnroll;   // per wave and stream
