@@ -521,6 +521,9 @@ __global__ void finalize_columns_kernel(const double* __restrict__ partials, int
 // block on y instead of four.  1 - e is exact in float (Sterbenz), and the rounding of W - e y, divided by
 // 1 - e ~ 1e-2..2.5e-3, stays at ~2e-6 of S: the same size as the rounding of 500..2000 sequential adds.
 // ------------------------------------------------------------------------------------------
+#ifndef HWK_STEPS_PRIO0
+#define HWK_STEPS_PRIO0 0
+#endif
 #ifndef HWK_ANGLE_BITS
 #define HWK_ANGLE_BITS 0
 #endif
@@ -582,11 +585,21 @@ __device__ __forceinline__ void ou_walk(const PhiloxKey& key, const PhiloxPath (
                     box_muller_parts(w0, w1, s0, sn0, cs0);
                     box_muller_parts(w2, w3, s1, sn1, cs1);
 #endif
+#if HWK_STEPS_PRIO0
+                    asm volatile("" : "+v"(s0), "+v"(sn0), "+v"(cs0), "+v"(s1), "+v"(sn1), "+v"(cs1));
+                    HWK_SETPRIO(0);
+                    asm volatile("" : "+v"(s0), "+v"(sn0), "+v"(cs0), "+v"(s1), "+v"(sn1), "+v"(cs1));
+#endif
                     const float a0 = __builtin_fmaf(e, sn0, cs0), a1 = __builtin_fmaf(e, sn1, cs1);
                     const float b0 = sn0 + cs0, b1 = sn1 + cs1;
                     const float t = __builtin_fmaf(e2, y[q], s0 * a0);
                     y[q] = __builtin_fmaf(e2, t, s1 * a1);
                     W[q] = __builtin_fmaf(s1, b1, __builtin_fmaf(s0, b0, W[q]));
+#if HWK_STEPS_PRIO0
+                    asm volatile("" : "+v"(y[q]), "+v"(W[q]));
+                    HWK_SETPRIO(1);
+                    asm volatile("" : "+v"(y[q]), "+v"(W[q]));
+#endif
                 }
             }
         };
