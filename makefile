@@ -58,6 +58,7 @@ microbench:
 	$(HIPCC) --offload-arch=gfx950 -O3 tools/valu_patterns.hip -o tools/bin/valu_patterns
 	$(HIPCC) --offload-arch=gfx950 -O3 tools/coissue_probe.hip -o tools/bin/coissue_probe
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -I $(PKG)/csrc tools/loop_lab.hip -o tools/bin/loop_lab
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -I $(PKG)/csrc tools/timeline_probe.hip -o tools/bin/timeline_probe
 
 run-all: run-q1 run-q2 run-q3
 
