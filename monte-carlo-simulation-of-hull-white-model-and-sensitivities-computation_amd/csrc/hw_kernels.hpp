@@ -206,7 +206,7 @@ __device__ __forceinline__ void normal4(const PhiloxKey& k, const PhiloxPath& pp
 #if HWK_PRIO_ROUNDS == 1
 #define HWK_SETPRIO_R(n) HWK_SETPRIO(n)
 #elif HWK_PRIO_ROUNDS == 2
-#define HWK_SETPRIO_R(n) HWK_SETPRIO((n) ? 2 : 0)
+#define HWK_SETPRIO_R(n) HWK_SETPRIO(((n) & 1) ? 2 : 0)
 #else
 #define HWK_SETPRIO_R(n) do { } while (0)
 #endif
@@ -225,7 +225,7 @@ __device__ __forceinline__ void pin4(uint32_t& a, uint32_t& b, uint32_t& c, uint
 // an SGPR) -- true for every wave that does not straddle a multiple of 2^32 paths.  Then word 2 after round 1,
 // hi(M0 j) ^ phi ^ k1[0], is wave-uniform as well, and the M1 multiply of round 2 runs on the scalar unit:
 // 16 vector multiplies and 18 bitwise ops per block instead of 17 and 19.
-template <bool UHI, bool RAISE = true>
+template <bool UHI, bool RAISE = true, int BASE = 0>
 __device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const PhiloxPath& pp, uint32_t a2s, uint32_t j,
                                                   uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
 {
@@ -240,7 +240,7 @@ __device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const Phil
         mulhilo(kM0, c0, hi0, lo0);                 // round 3
         mulhilo(kM1, c2, hi1, lo1);
         pin2(hi0, hi1);
-        HWK_SETPRIO(0);
+        HWK_SETPRIO(BASE + 0);
         pin2(hi0, hi1);
         c0 = hi1 ^ (slo ^ k.s_k0_2);
     } else {
@@ -253,7 +253,7 @@ __device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const Phil
         mulhilo(kM0, c0, hi0, lo0);                 // round 3
         mulhilo(kM1, c2, hi1, lo1);
         pin2(hi0, hi1);
-        HWK_SETPRIO(0);
+        HWK_SETPRIO(BASE + 0);
         pin2(hi0, hi1);
         c0 = xor3(hi1, c1, k.k0[2]);
     }
@@ -263,12 +263,12 @@ __device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const Phil
 #pragma unroll
     for (int r = 3; r < 10; r++) {                  // rounds 4..10: multiplies at priority 1, xors at 0
         pin2(c0, c2);
-        HWK_SETPRIO_R(1);
+        HWK_SETPRIO_R(BASE + 1);
         pin2(c0, c2);
         mulhilo(kM0, c0, hi0, lo0);
         mulhilo(kM1, c2, hi1, lo1);
         pin2(hi0, hi1);
-        HWK_SETPRIO_R(0);
+        HWK_SETPRIO_R(BASE + 0);
         pin2(hi0, hi1);
         c0 = xor3(hi1, c1, k.k0[r]);
         c1 = lo1;
@@ -277,7 +277,7 @@ __device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const Phil
     }
     if constexpr (RAISE) {
         pin4(c0, c1, c2, c3);
-        HWK_SETPRIO(1);
+        HWK_SETPRIO(BASE + 1);
         pin4(c0, c1, c2, c3);
     }
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
@@ -521,6 +521,9 @@ __global__ void finalize_columns_kernel(const double* __restrict__ partials, int
 // block on y instead of four.  1 - e is exact in float (Sterbenz), and the rounding of W - e y, divided by
 // 1 - e ~ 1e-2..2.5e-3, stays at ~2e-6 of S: the same size as the rounding of 500..2000 sequential adds.
 // ------------------------------------------------------------------------------------------
+#ifndef HWK_PROGRESS_PRIO
+#define HWK_PROGRESS_PRIO 0
+#endif
 #ifndef HWK_STEPS_PRIO0
 #define HWK_STEPS_PRIO0 0
 #endif
@@ -559,15 +562,16 @@ __device__ __forceinline__ void ou_walk(const PhiloxKey& key, const PhiloxPath (
         float W[ILP];
 #pragma unroll
         for (int q = 0; q < ILP; q++) W[q] = 0.0f;
-        auto blocks = [&](auto tag) {
+        auto blocks_range = [&](auto tag, auto base_tag, int j0, int j1) {
             constexpr bool UHI = decltype(tag)::value;
-            for (int j = 0; j < nblk; j++) {
+            constexpr int BASE = decltype(base_tag)::value;
+            for (int j = j0; j < j1; j++) {
 #pragma unroll
                 for (int q = 0; q < ILP; q++) {
                     uint32_t w0, w1, w2, w3;
                     float s0, sn0, cs0, s1, sn1, cs1;
 #if HWK_CVT_AT_PRIO0
-                    philox_block_prio<UHI, false>(key, pp[q], a2s[q], (uint32_t)j, w0, w1, w2, w3);
+                    philox_block_prio<UHI, false, BASE>(key, pp[q], a2s[q], (uint32_t)j, w0, w1, w2, w3);
                     constexpr float kInv = 2.3283064e-10f;
                     float u0 = __builtin_fmaf((float)w0, kInv, kInv), v0 = __builtin_fmaf((float)w1, kInv, kInv);
                     float u1 = __builtin_fmaf((float)w2, kInv, kInv), v1 = __builtin_fmaf((float)w3, kInv, kInv);
@@ -581,7 +585,7 @@ __device__ __forceinline__ void ou_walk(const PhiloxKey& key, const PhiloxPath (
                     sn1 = __builtin_amdgcn_sinf(v1);
                     cs1 = __builtin_amdgcn_cosf(v1);
 #else
-                    philox_block_prio<UHI>(key, pp[q], a2s[q], (uint32_t)j, w0, w1, w2, w3);
+                    philox_block_prio<UHI, true, BASE>(key, pp[q], a2s[q], (uint32_t)j, w0, w1, w2, w3);
                     box_muller_parts(w0, w1, s0, sn0, cs0);
                     box_muller_parts(w2, w3, s1, sn1, cs1);
 #endif
@@ -602,6 +606,19 @@ __device__ __forceinline__ void ou_walk(const PhiloxKey& key, const PhiloxPath (
 #endif
                 }
             }
+        };
+        auto blocks = [&](auto tag) {
+#if HWK_PROGRESS_PRIO
+            // experiment: the first half of a wave's life at priorities 2/3, the second at 0/1, so that waves
+            // that are behind overtake the ones ahead (the arbiter otherwise favours the oldest wave)
+            const int mid = nblk >> 1;
+            __builtin_amdgcn_s_setprio(3);
+            blocks_range(tag, std::integral_constant<int, 2>{}, 0, mid);
+            __builtin_amdgcn_s_setprio(1);
+            blocks_range(tag, std::integral_constant<int, 0>{}, mid, nblk);
+#else
+            blocks_range(tag, std::integral_constant<int, 0>{}, 0, nblk);
+#endif
         };
         if (uhi) blocks(std::true_type{});
         else blocks(std::false_type{});
