@@ -335,7 +335,9 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
     // float, whole Philox blocks, maturities on half-block boundaries: the blocked kernel, P pairs per thread
     // (P = 4 / 2 once the batch still fills the chip's 8 waves per SIMD twice over: measured, one round of fat
     // threads is no faster than two rounds of thin ones)
-    if (std::is_same<REAL, float>::value && p.n_steps % 4 == 0 && stride % 2 == 0 && stride >= 4 && !c->curve_generic) {
+    // (the (y, W) form needs (1 - e) sqrt(n_steps) >= 0.05, see ou_walk)
+    if (std::is_same<REAL, float>::value && p.n_steps % 4 == 0 && stride % 2 == 0 && stride >= 4 && !c->curve_generic &&
+        (1.0 - (double)(float)k.e) * std::sqrt((double)p.n_steps) >= 0.05) {
         const int64_t resident = (int64_t)c->prop.multiProcessorCount * 2048;
         const int P = n_pairs >= 8 * resident ? 4 : n_pairs >= 4 * resident ? 2 : 1;   // keep >= 2 rounds of waves
         const Geometry g = geometry(c, n_pairs, P, true);

@@ -557,7 +557,15 @@ __device__ __forceinline__ void ou_walk(const PhiloxKey& key, const PhiloxPath (
 #pragma unroll
     for (int q = 0; q < ILP; q++) uhi = philox_uniform_hi(pp[q], a2s[q]) && uhi;
     HWK_SETPRIO(1);
-    if constexpr (sizeof(REAL) == sizeof(float)) {
+    // The (y, W) form divides by 1 - e, which amplifies the rounding of W - e y by ~ 1 / ((1 - e) sqrt(n_steps)).
+    // Measured against the double oracle (tools/weak_reversion_probe.py): no excess over the per-step form at
+    // (1 - e) sqrt(n) = 0.11 (a = 0.5), 1e-5 of excess at 0.022 (a = 0.1).  It is used from 0.05 up -- every
+    // reference configuration: 0.22 at 1000 steps, 0.11 at 4000 -- weak mean reversion or very fine grids fall back
+    // to the per-step form.
+    bool wform = false;
+    if constexpr (sizeof(REAL) == sizeof(float)) wform = (1.0f - (float)e) * sqrtf((float)n_steps) >= 0.05f;
+    if (wform) {
+      if constexpr (sizeof(REAL) == sizeof(float)) {
         const float e2 = e * e;
         float W[ILP];
 #pragma unroll
@@ -639,6 +647,7 @@ __device__ __forceinline__ void ou_walk(const PhiloxKey& key, const PhiloxPath (
         const float inv = 1.0f / (1.0f - e);
 #pragma unroll
         for (int q = 0; q < ILP; q++) S[q] = (W[q] - e * y[q]) * inv;
+      }
     } else {
         auto blocks = [&](auto tag) {
             constexpr bool UHI = decltype(tag)::value;

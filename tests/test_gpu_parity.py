@@ -476,3 +476,25 @@ def test_full_size_properties_of_the_multi_gpu_shares(setup, hwmc_mod):
     v32 = e32.simulate_sensitivity(n5, 7) / n5
     v64 = e64.simulate_sensitivity(n5, 7) / n5
     assert v32 == pytest.approx(v64, rel=REL_F32) and v64 == pytest.approx(0.230244, abs=1e-3)
+
+
+def test_weak_mean_reversion_falls_back_to_the_per_step_form(hwmc_mod, oracle_mod):
+    """The float (y, W) form of the time loop divides by 1 - e and is used only while (1 - e) sqrt(steps) >= 0.05
+    (ou_walk).  Away from the reference's a = 1 every float32 implementation -- the float32 oracle included -- sits
+    ~1e-5 from the double oracle, so the bar here is 5e-5 against the DOUBLE oracle on the same draws: a = 0.02 and
+    0.1 run the per-step fallback, a = 0.5 the blocked form; the reference stepper must agree as well."""
+    n = 20000
+    for a in (0.02, 0.1, 0.5):
+        p = hwmc_mod.default_params("readme")
+        p.a = a
+        o64 = oracle_mod.Oracle("readme", precision="f64")
+        o64.m.a = a
+        e = hwmc_mod.HullWhiteEngine(p, device=0)
+        P, f = hwmc_mod.analytic_curve(p)
+        e.load_market_data(P, f)
+        want = o64.zbc_moments(P, f, n, 3)
+        np.testing.assert_allclose(e.simulate_ZBC_control_variate(n, 3), want, rtol=5e-5)
+        np.testing.assert_allclose(e.simulate_ZBC_control_variate(n, 3, stepper=hwmc_mod.HW_STEPPER_REFERENCE), want, rtol=5e-5)
+        assert e.simulate_sensitivity(n, 4) == pytest.approx(o64.vega_pathwise(P, f, n, 4), rel=2e-4)
+        np.testing.assert_allclose(e.simulate_zcb(n, 5), o64.zcb_curve(n, 5), rtol=5e-5)
+        e.close()
