@@ -498,3 +498,40 @@ def test_weak_mean_reversion_falls_back_to_the_per_step_form(hwmc_mod, oracle_mo
         assert e.simulate_sensitivity(n, 4) == pytest.approx(o64.vega_pathwise(P, f, n, 4), rel=2e-4)
         np.testing.assert_allclose(e.simulate_zcb(n, 5), o64.zcb_curve(n, 5), rtol=5e-5)
         e.close()
+
+
+def test_random_parameter_sweep_against_the_double_oracle(hwmc_mod, oracle_mod):
+    """24 seeded random parameter sets (mean reversion, volatility, grid, maturity grid, option dates, strike): the
+    float32 engine -- whichever kernel variant the parameters select (blocked or per-step time loop, blocked or generic
+    curve kernel, tails of 1..3 steps, P pairs per thread) -- stays within 1e-4 of the DOUBLE oracle on the same
+    draws and the float64 engine within 2e-6, for the ZBC moments, the Vega sum and the curve."""
+    rng = np.random.default_rng(20240613)
+    for case in range(24):
+        n_mat = int(rng.choice([11, 21, 51, 101]))
+        n_steps = (n_mat - 1) * int(rng.choice([2, 5, 8, 10, 25, 40]))
+        a = float(rng.choice([0.05, 0.3, 1.0, 2.5]))
+        sigma = float(rng.uniform(0.02, 0.2))
+        S1 = max(float(rng.uniform(0.3, 7.0)), 2.0 * 10.0 / n_steps)                # at least two time steps
+        S2 = float(rng.uniform(S1 + 0.5, 10.0))
+        seed = int(rng.integers(1, 2 ** 40))
+        n = int(rng.integers(500, 3000))
+        res = {}
+        for prec in ("f32", "f64"):
+            p = hwmc_mod.default_params("readme", n_steps=n_steps, n_mat=n_mat, precision=prec, sigma=sigma)
+            p.a = a
+            e = hwmc_mod.HullWhiteEngine(p, device=0)
+            P, f = hwmc_mod.analytic_curve(p)
+            e.load_market_data(P, f)
+            o = oracle_mod.Oracle("readme", n_steps=n_steps, n_mat=n_mat, sigma=sigma, precision="f64")
+            o.m.a = a
+            K = float(np.interp(S2, np.linspace(0, 10, n_mat), P) / np.interp(S1, np.linspace(0, 10, n_mat), P))   # at the money forward
+            tol = 1e-4 if prec == "f32" else 2e-6
+            ctx = "case %d %s: n_steps=%d n_mat=%d a=%.2f sigma=%.3f S1=%.3f S2=%.3f n=%d" % (case, prec, n_steps, n_mat, a, sigma, S1, S2, n)
+            got = e.simulate_ZBC_control_variate(n, seed, S1=S1, S2=S2, K=K)
+            assert np.all(np.isfinite(got)), ctx
+            np.testing.assert_allclose(got, o.zbc_moments(P, f, n, seed, S1=S1, S2=S2, K=K), rtol=tol, err_msg=ctx)
+            v = e.simulate_sensitivity(n, seed + 1, S1=S1, S2=S2, K=K)
+            vo = o.vega_pathwise(P, f, n, seed + 1, S1=S1, S2=S2, K=K)
+            assert abs(v - vo) <= 20 * tol * max(abs(vo), n * 1e-3), ctx          # a sum of signed terms: absolute floor
+            np.testing.assert_allclose(e.simulate_zcb(n, seed + 2), o.zcb_curve(n, seed + 2), rtol=tol, err_msg=ctx)
+            e.close()
