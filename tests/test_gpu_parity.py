@@ -535,3 +535,31 @@ def test_random_parameter_sweep_against_the_double_oracle(hwmc_mod, oracle_mod):
             assert abs(v - vo) <= 20 * tol * max(abs(vo), n * 1e-3), ctx          # a sum of signed terms: absolute floor
             np.testing.assert_allclose(e.simulate_zcb(n, seed + 2), o.zcb_curve(n, seed + 2), rtol=tol, err_msg=ctx)
             e.close()
+
+
+def test_random_seeds_offsets_and_counts(setup, hwmc_mod):
+    """40 seeded random (seed, path_offset, count) triples at the reference configuration -- 64-bit seeds, offsets
+    anywhere in 2^64 including just below multiples of 2^32, ragged counts -- ZBC moments of both steppers, the
+    two-scenario FD launch and the batched runs against the float32 oracle at the north-star tolerance."""
+    e, o, P, f = setup("readme")
+    rng = np.random.default_rng(7)
+    for case in range(40):
+        seed = int(rng.integers(0, 2 ** 63)) * 2 + int(rng.integers(0, 2))
+        kind = case % 4
+        if kind == 0:
+            off = int(rng.integers(0, 2 ** 63)) * 2
+        elif kind == 1:
+            off = int(rng.integers(1, 2 ** 31)) * 2 ** 32 - int(rng.integers(1, 200))     # a wave straddles 2^32 k
+        elif kind == 2:
+            off = int(rng.integers(0, 2 ** 20))
+        else:
+            off = 2 ** 64 - 1 - int(rng.integers(5000, 10 ** 6))                          # near the top of the id space
+        n = int(rng.integers(1, 700))
+        ctx = "case %d: seed=%d off=%d n=%d" % (case, seed, off, n)
+        want = o.zbc_moments(P, f, n, seed, path_offset=off)
+        np.testing.assert_allclose(e.simulate_ZBC_control_variate(n, seed, path_offset=off), want, rtol=REL_F32, err_msg=ctx)
+        if case % 5 == 0:
+            np.testing.assert_allclose(e.simulate_ZBC_control_variate(n, seed, path_offset=off, stepper=hwmc_mod.HW_STEPPER_REFERENCE),
+                                       want, rtol=REL_F32, err_msg=ctx)
+            runs = e.simulate_ZBC_runs(n, seed % 2 ** 62, n_runs=3, seed_stride=12345, path_offset=off)
+            np.testing.assert_allclose(runs[1], o.zbc_moments(P, f, n, seed % 2 ** 62 + 12345, path_offset=off), rtol=REL_F32, err_msg=ctx)
