@@ -816,24 +816,31 @@ zbc_reference_kernel(const ZbcRefArgs a, const float* __restrict__ drift, double
         if (!valid) p = 0;
         const PhiloxPath pp = philox_path(key, a.path_offset + (uint64_t)p);
         float r1 = a.r0, r2 = a.r0, I1 = 0.0f, I2 = 0.0f;           // common.cuh:318-319
+        uint32_t a2s;
+        const bool uhi = philox_uniform_hi(pp, a2s);                  // wave-uniform: scalar round-2 multiply
         HWK_SETPRIO(1);
-        for (int i = 0; i < a.n_steps; i += 4) {                     // common.cuh:325-332
-            float g[4];
-            normal4_prio(vkey, pp, (uint32_t)(i >> 2), g);
+        auto walk = [&](auto tag) {
+            constexpr bool UHI = decltype(tag)::value;
+            for (int i = 0; i < a.n_steps; i += 4) {                 // common.cuh:325-332
+                float g[4];
+                normal4_prio<UHI>(vkey, pp, a2s, (uint32_t)(i >> 2), g);
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                if (i + c < a.n_steps) {
-                    const float d = tab[i + c];
-                    const float sG = a.sig_st * g[c];
-                    const float r1n = __builtin_fmaf(r1, a.e, d + sG);   // common.cuh:241
-                    I1 += (r1 + r1n) * half_dt;                           // common.cuh:242; 0.5f*x*dt == x*(0.5f*dt) bit for bit
-                    r1 = r1n;
-                    const float r2n = __builtin_fmaf(r2, a.e, d - sG);
-                    I2 += (r2 + r2n) * half_dt;
-                    r2 = r2n;
+                for (int c = 0; c < 4; c++) {
+                    if (i + c < a.n_steps) {
+                        const float d = tab[i + c];
+                        const float sG = a.sig_st * g[c];
+                        const float r1n = __builtin_fmaf(r1, a.e, d + sG);   // common.cuh:241
+                        I1 += (r1 + r1n) * half_dt;                           // common.cuh:242; 0.5f*x*dt == x*(0.5f*dt) bit for bit
+                        r1 = r1n;
+                        const float r2n = __builtin_fmaf(r2, a.e, d - sG);
+                        I2 += (r2 + r2n) * half_dt;
+                        r2 = r2n;
+                    }
                 }
             }
-        }
+        };
+        if (uhi) walk(std::true_type{});
+        else walk(std::false_type{});
         HWK_SETPRIO(0);
         const float P1 = a.A * hw_exp2(-a.B * r1 * kLog2e);            // common.cuh:337-338
         const float P2 = a.A * hw_exp2(-a.B * r2 * kLog2e);
@@ -891,30 +898,37 @@ zcb_curve_kernel(const ZcbArgs<REAL> a, double* __restrict__ partials)
         if (!valid) p = 0;
         const PhiloxPath pp = philox_path(key, a.path_offset + (uint64_t)p);
         REAL y = 0, S = 0;
-        int countdown = a.stride, m = 0;
+        uint32_t a2s;
+        const bool uhi = philox_uniform_hi(pp, a2s);
         HWK_SETPRIO(1);
-        for (int i = 0; i < a.n_steps; i += 4) {
-            float g[4];
-            normal4_prio(vkey, pp, (uint32_t)(i >> 2), g);
+        auto walk = [&](auto tag) {
+            constexpr bool UHI = decltype(tag)::value;
+            int countdown = a.stride, m = 0;
+            for (int i = 0; i < a.n_steps; i += 4) {
+                float g[4];
+                normal4_prio<UHI>(vkey, pp, a2s, (uint32_t)(i >> 2), g);
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                if (i + c < a.n_steps) {                                   // wave-uniform
-                    y = hw_fma(y, a.e, (REAL)g[c]);
-                    S += y;
-                    if (--countdown == 0) {                                // market_data.cuh:57
-                        countdown = a.stride;
-                        m++;
-                        if (m < a.n_mat) {                                 // market_data.cuh:59
-                            const REAL z = a.cz * (S - (REAL)0.5 * y);
-                            REAL q = hw_exp2(z) + hw_exp2(-z);             // market_data.cuh:60
-                            if (!valid) q = 0;
-                            const REAL qs = curve_wave_sum(q);             // market_data.cuh:61
-                            if (lane == kWave - 1) row[m] += (double)qs;   // market_data.cuh:62-64
+                for (int c = 0; c < 4; c++) {
+                    if (i + c < a.n_steps) {                               // wave-uniform
+                        y = hw_fma(y, a.e, (REAL)g[c]);
+                        S += y;
+                        if (--countdown == 0) {                            // market_data.cuh:57
+                            countdown = a.stride;
+                            m++;
+                            if (m < a.n_mat) {                             // market_data.cuh:59
+                                const REAL z = a.cz * (S - (REAL)0.5 * y);
+                                REAL q = hw_exp2(z) + hw_exp2(-z);         // market_data.cuh:60
+                                if (!valid) q = 0;
+                                const REAL qs = curve_wave_sum(q);         // market_data.cuh:61
+                                if (lane == kWave - 1) row[m] += (double)qs;   // market_data.cuh:62-64
+                            }
                         }
                     }
                 }
             }
-        }
+        };
+        if (uhi) walk(std::true_type{});
+        else walk(std::false_type{});
         HWK_SETPRIO(0);
     }
     __syncthreads();
