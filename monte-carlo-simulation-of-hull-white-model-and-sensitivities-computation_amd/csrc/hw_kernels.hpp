@@ -511,8 +511,8 @@ __global__ void finalize_columns_kernel(const double* __restrict__ partials, int
 // int r = cI +- dt s (S - y/2) are reconstructed in the epilogues from host-computed m_n, cI_n (hw_model.hpp,
 // mean_path).
 //
-// Generic form (double): one fma + one add per step.
-// float form: a whole Philox block (4 steps) at a time, on the raw Box-Muller parts.  With g0 = s0 sin0,
+// Per-step form (double; float when the (y, W) form below would lose precision): one fma + one add per step.
+// float (y, W) form: a whole Philox block (4 steps) at a time, on the raw Box-Muller parts.  With g0 = s0 sin0,
 // g1 = s0 cos0, g2 = s1 sin1, g3 = s1 cos1:
 //     y4 = e^4 y0 + e^2 s0 (e sin0 + cos0) + s1 (e sin1 + cos1)
 //     W4 = W0 + s0 (sin0 + cos0) + s1 (sin1 + cos1),            W_n = sum of the normals
@@ -520,6 +520,8 @@ __global__ void finalize_columns_kernel(const double* __restrict__ partials, int
 // That is 10 single-rate ops per block instead of 12 (4 products, 4 fma, 4 adds) and two dependent fmas per
 // block on y instead of four.  1 - e is exact in float (Sterbenz), and the rounding of W - e y, divided by
 // 1 - e ~ 1e-2..2.5e-3, stays at ~2e-6 of S: the same size as the rounding of 500..2000 sequential adds.
+// (Guard and measurements for weaker mean reversion: see the comment in ou_walk.)
+// The HWK_* macros below switch on experiments that were measured and NOT adopted.
 // ------------------------------------------------------------------------------------------
 #ifndef HWK_PROGRESS_PRIO
 #define HWK_PROGRESS_PRIO 0
