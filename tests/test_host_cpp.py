@@ -53,3 +53,14 @@ def test_cpp_writers_follow_the_reference_formats(probe, hwmc_mod):
     raw = np.fromfile(out / "probe.bin", dtype=np.float32)
     P, _ = hwmc_mod.analytic_curve(hwmc_mod.default_params("readme"))
     assert np.array_equal(raw, P)                                                              # common.cuh:144-153
+
+
+def test_integration_md_call_shapes_compile_and_link(tmp_path, hwmc_mod):
+    """Every call sequence INTEGRATION.md shows a maintainer of the reference (Q1, Q2b, the 20-run harnesses, Q3,
+    the in-process communicator) compiles against include/hw_mc.h and links against libhw_hip.so (nothing is run:
+    there is no GPU here)."""
+    exe = str(tmp_path / "integration_shapes")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-Wno-unused-variable", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "integration_shapes.cpp"), "-o", exe,
+                           "-L" + PKG, "-lhw_hip", "-Wl,-rpath," + PKG])
+    assert os.path.exists(exe)
