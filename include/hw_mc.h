@@ -193,7 +193,7 @@ int  hw_profile_read(hw_ctx* ctx, float* ms, int32_t cap, int32_t* n_out);
  * in-kernel s_memtime / s_memrealtime probe in workgroup 0 (read after the launch completed). */
 int  hw_profile_clock(hw_ctx* ctx, double* shader_mhz);
 
-int  hw_get_kernel_info(hw_ctx* ctx, const char* kernel /* "zbc" | "zbc_ref" | "zcb" | "vega" */,
+int  hw_get_kernel_info(hw_ctx* ctx, const char* kernel /* "zbc" | "zbc_ref" | "zcb" | "zcb_blocked" | "vega" */,
                         hw_kernel_info* out);
 
 /* ---- several GPUs in one process ---------------------------------------------------------------

@@ -878,6 +878,8 @@ int hw_get_kernel_info(hw_ctx* c, const char* kernel, hw_kernel_info* out)
         fn = c->table_in_lds ? (const void*)hwk::zbc_reference_kernel<1> : (const void*)hwk::zbc_reference_kernel<0>;
     else if (!strcmp(kernel, "zcb"))
         fn = f64 ? (const void*)hwk::zcb_curve_kernel<double> : (const void*)hwk::zcb_curve_kernel<float>;
+    else if (!strcmp(kernel, "zcb_blocked"))
+        fn = (const void*)hwk::zcb_curve_blocked_kernel<1>;
     else if (!strcmp(kernel, "vega"))
         fn = f64 ? (const void*)hwk::vega_pathwise_kernel<double, 1> : (const void*)hwk::vega_pathwise_kernel<float, 1>;
     else

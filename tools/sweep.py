@@ -29,7 +29,7 @@ def main():
     P, f = hwmc.analytic_curve(p)
     e.load_market_data(P, f)
     print(e.device_info())
-    for k in ("zbc", "zbc_ref", "zcb", "vega"):
+    for k in ("zbc", "zbc_ref", "zcb", "zcb_blocked", "vega"):
         print(k, e.kernel_info(k))
     variants = []
     for stepper in ("superposed", "reference"):
