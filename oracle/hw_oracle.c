@@ -11,6 +11,8 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+
+#define ORA_CHUNK 512   /* pairs per partial sum: fixes the order of the floating-point additions */
 #endif
 
 /* ======================================================================================== *

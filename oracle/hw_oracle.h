@@ -29,6 +29,10 @@
  * (1) the deterministic constants/tables of the reference's host code (SURVEY.md section 2.3 KATs),
  * (2) exact Hull-White closed forms, and (3) the reference's published outputs
  * (README.md:15-56) as statistical targets under theta profile "readme".
+ *
+ * SUMMATION ORDER.  The Monte Carlo sums are formed per fixed chunk of 512 pairs (ORA_CHUNK) and the chunks are
+ * added in index order, so every result is bit-identical whatever the number of OpenMP threads or the schedule
+ * (tests/golden/gen_golden.py regenerates the committed fixture byte for byte).
  */
 #ifndef HW_ORACLE_H
 #define HW_ORACLE_H

@@ -89,6 +89,19 @@ def test_tables_f32_emulation_numpy(oracle_mod):
         assert d[i] == want
 
 
+def test_oracle_sums_do_not_depend_on_the_thread_count(oracle_mod, hwmc_mod):
+    """Fixed chunks added in index order (oracle/hw_oracle.h, SUMMATION ORDER): 1, 3 and all threads agree bit for bit."""
+    p = hwmc_mod.default_params("readme")
+    P, f = hwmc_mod.analytic_curve(p)
+    o = oracle_mod.Oracle("readme")
+    zs = [o.zbc_moments(P, f, 2500, 3, n_threads=t) for t in (1, 3, o.max_threads())]
+    assert all(np.array_equal(zs[0], z) for z in zs)
+    cs = [o.zcb_curve(1300, 5, n_threads=t) for t in (1, 3, o.max_threads())]
+    assert all(np.array_equal(cs[0], c) for c in cs)
+    vs = [o.vega_pathwise(P, f, 2500, 4, n_threads=t) for t in (1, 3, o.max_threads())]
+    assert vs[0] == vs[1] == vs[2]
+
+
 def test_golden_matches_oracle(oracle_mod, hwmc_mod, golden):
     """The committed fixture is what the oracle produces today (guards accidental drift)."""
     for case in golden["cases"]:
