@@ -563,3 +563,29 @@ def test_random_seeds_offsets_and_counts(setup, hwmc_mod):
                                        want, rtol=REL_F32, err_msg=ctx)
             runs = e.simulate_ZBC_runs(n, seed % 2 ** 62, n_runs=3, seed_stride=12345, path_offset=off)
             np.testing.assert_allclose(runs[1], o.zbc_moments(P, f, n, seed % 2 ** 62 + 12345, path_offset=off), rtol=REL_F32, err_msg=ctx)
+
+
+def test_single_launch_ticket_finish(setup, hwmc_mod, monkeypatch):
+    """HWMC_SINGLE_LAUNCH=1 (read by hw_create): the grid-wide sums are finished inside the path kernel by the last
+    workgroup to arrive (sharded tickets, self re-arming).  Same sums as the default two-launch finish to rounding,
+    bit-reproducible, for grids from one workgroup to thousands, many launches in a row."""
+    e, o, P, f = setup("readme")
+    monkeypatch.setenv("HWMC_SINGLE_LAUNCH", "1")
+    p = hwmc_mod.default_params("readme")
+    t = hwmc_mod.HullWhiteEngine(p, device=0)
+    monkeypatch.delenv("HWMC_SINGLE_LAUNCH")
+    t.load_market_data(P, f)
+    for n in (1, 200, 256 * 7, 256 * 8 + 3, 100_000, (1 << 20) + 77):            # 1, 1, 7, 9, 391, 2049 workgroups
+        a = t.simulate_ZBC_control_variate(n, 31)
+        np.testing.assert_allclose(a, e.simulate_ZBC_control_variate(n, 31), rtol=1e-13)
+        assert np.array_equal(a, t.simulate_ZBC_control_variate(n, 31))             # tickets re-armed, fixed order
+    for k in range(12):                                                            # back to back, varying sizes
+        n = 1000 + 977 * k
+        np.testing.assert_allclose(t.simulate_ZBC_control_variate(n, k), e.simulate_ZBC_control_variate(n, k), rtol=1e-13)
+    assert t.simulate_sensitivity(50_000, 9) == pytest.approx(e.simulate_sensitivity(50_000, 9), rel=1e-13)
+    sig = [0.099, 0.101]
+    dm = [hwmc_mod.HW_DRIFT_SHIFTED] * 2
+    np.testing.assert_allclose(t.simulate_ZBC_scenarios(30_000, 5, sig, dm), e.simulate_ZBC_scenarios(30_000, 5, sig, dm), rtol=1e-13)
+    np.testing.assert_allclose(t.simulate_ZBC_control_variate(30_000, 5, stepper=hwmc_mod.HW_STEPPER_REFERENCE),
+                               e.simulate_ZBC_control_variate(30_000, 5, stepper=hwmc_mod.HW_STEPPER_REFERENCE), rtol=1e-13)
+    t.close()
