@@ -75,3 +75,33 @@ def test_usable_cores_never_exceeds_the_openmp_default(oracle_mod):
     n, how = oracle_mod.usable_cores(1000)
     assert 1 <= n <= 1000 and how in ("omp_get_max_threads", "sched_getaffinity", "cgroup cpu quota")
     assert oracle_mod.usable_cores(1) == (1, "omp_get_max_threads")
+
+
+@pytest.mark.parametrize("profile", ["head", "readme"])
+def test_analytic_curve_against_numerical_quadrature(hwmc_mod, profile):
+    """hw_analytic_curve (the synthetic market input of bench.py and of most parity tests) against an independent
+    evaluation: for dr = (theta(t) - a r) dt + sigma dW,  int_0^T r  is Gaussian with
+    mean r0 B(0,T) + int_0^T theta(u) B(u,T) du  and variance sigma^2 int_0^T B(u,T)^2 du, B(u,T) = (1 - e^{-a(T-u)})/a,
+    so P(0,T) = exp(-mean + variance/2) and f(0,T) = r0 e^{-aT} + int_0^T theta(u) e^{-a(T-u)} du - sigma^2 B(0,T)^2 / 2.
+    The integrals are done with scipy.integrate.quad on the piecewise-linear theta."""
+    from scipy.integrate import quad
+    p = hwmc_mod.default_params(profile)
+    P, f = hwmc_mod.analytic_curve(p)
+    a, s, r0 = p.a, p.sigma, p.r0
+
+    def theta(u):
+        return p.th_a1 + p.th_b1 * u if u < p.th_break else p.th_a2 + p.th_b2 * u
+
+    def B(u, T):
+        return (1.0 - math.exp(-a * (T - u))) / a
+
+    for j in (1, 17, 50, 51, 77, 100):
+        T = j * p.T_final / (p.n_mat - 1)
+        pts = [p.th_break] if T > p.th_break else None
+        mean = r0 * B(0.0, T) + quad(lambda u: theta(u) * B(u, T), 0.0, T, points=pts, epsabs=1e-13, epsrel=1e-13)[0]
+        var = s * s * quad(lambda u: B(u, T) ** 2, 0.0, T, epsabs=1e-14, epsrel=1e-13)[0]
+        fwd = r0 * math.exp(-a * T) + quad(lambda u: theta(u) * math.exp(-a * (T - u)), 0.0, T, points=pts,
+                                           epsabs=1e-13, epsrel=1e-13)[0] - 0.5 * s * s * B(0.0, T) ** 2
+        assert float(P[j]) == pytest.approx(math.exp(-mean + 0.5 * var), rel=2e-7)      # float32 storage
+        assert float(f[j]) == pytest.approx(fwd, rel=5e-7, abs=1e-8)
+    assert P[0] == 1.0 and float(f[0]) == pytest.approx(r0, rel=1e-7)
