@@ -105,3 +105,24 @@ def test_analytic_curve_against_numerical_quadrature(hwmc_mod, profile):
         assert float(P[j]) == pytest.approx(math.exp(-mean + 0.5 * var), rel=2e-7)      # float32 storage
         assert float(f[j]) == pytest.approx(fwd, rel=5e-7, abs=1e-8)
     assert P[0] == 1.0 and float(f[0]) == pytest.approx(r0, rel=1e-7)
+
+
+def test_closed_form_targets_of_the_parity_tests_are_derived_not_magic(hwmc_mod):
+    """The constants the statistical parity tests compare against (tests/test_oracle.py, tests/test_gpu_parity.py:
+    ZBC 0.03544557 and Vega 0.230244 under the readme profile) are Jamshidian's bond-option formula on the exact
+    curve and its derivative in sigma with the market curves held fixed -- the quantity both the pathwise and the
+    shifted-drift finite-difference estimators of the reference target (3_sens:15-19, 374-398)."""
+    from scipy.stats import norm
+    p = hwmc_mod.default_params("readme")
+    P, _ = hwmc_mod.analytic_curve(p)
+    a, S1, S2, K = p.a, 5.0, 10.0, float(np.exp(np.float32(-0.1)))
+    P1, P2 = float(P[50]), float(P[100])
+    B = (1.0 - math.exp(-a * (S2 - S1))) / a
+
+    def price(sig):
+        sp = sig * math.sqrt((1.0 - math.exp(-2.0 * a * S1)) / (2.0 * a)) * B
+        h = math.log(P2 / (K * P1)) / sp + 0.5 * sp
+        return P2 * norm.cdf(h) - K * P1 * norm.cdf(h - sp)
+
+    assert price(p.sigma) == pytest.approx(0.03544557, abs=5e-8)
+    assert (price(p.sigma + 1e-5) - price(p.sigma - 1e-5)) / 2e-5 == pytest.approx(0.230244, abs=2e-6)
