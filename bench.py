@@ -40,11 +40,15 @@ sys.path.insert(0, ROOT)
 #  measured by tools/valu_rates.hip on MI355X: full rate 2, half rate 4, quarter rate 8).
 VALU_MODEL = {
     "superposed": {"full": 30, "half": 21, "quarter": 8},   # 14 bitop3,4 xor,4 fmamk,2 mul,4 fma/fmac,2 add | 16 mad_u64,4 cvt,1 pk_fma | 2 log,2 sqrt,2 sin,2 cos
-    "reference": {"full": 64, "half": 21, "quarter": 8},    # (per-lane round-2 multiply: 17 mad_u64)    # + per-step: sG mul, 2 add, 2 fma, 2 add, 2 mul/fma pairs on two legs
+    "reference": {"full": 64, "half": 20, "quarter": 8},    # + per step: sG mul, 2 add, 2 fma, 2 add, 2 mul/fma pairs on two legs
+    # double stepper: per-step fmac_f64 + add_f64 on converted normals:
+    # 14 bitop3,4 xor,4 fmamk,4 mul | 16 mad_u64,4 cvt_u32,4 cvt_f64,4 fmac_f64,4 add_f64 | 8 transcendentals
+    "superposed_f64": {"full": 26, "half": 32, "quarter": 8},
 }
 # Issue costs measured on MI355X at 8 waves/SIMD (tools/valu_rates.hip, tools/valu_patterns.hip; profiles/):
 # "full-rate" ops sustain one per 2.3 cycles (two waves issue side by side; one wave alone: 4.7),
-# v_mad_u64_u32 4.45, v_cvt_f32_u32 4.24, transcendentals 8.1.  The nominal 2/4/8 model is unreachable.
+# v_mad_u64_u32 4.45, v_cvt_f32_u32 4.24, transcendentals 8.1 -- each class measured alone; in the mixed loop part of
+# v_cvt hides under single-rate ops (tools/coissue_probe.hip) and the kernel runs at the nominal 2/4/8 model.
 MEASURED_ISSUE = {"full": 2.3, "half": 4.4, "quarter": 8.1}
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 V100_PUBLISHED_MPATHS = 1064.0  # BASELINE.md section 1 (reference README.md:44,162; one V100)
@@ -318,7 +322,7 @@ def main():
         other = hwmc.HW_STEPPER_REFERENCE if a.stepper == "superposed" else hwmc.HW_STEPPER_SUPERPOSED
         if not (other == hwmc.HW_STEPPER_REFERENCE and a.precision != "f32"):
             for i in range(3):
-                enqueue(i, 5, scratch[i], which=other)
+                enqueue(i, 5, scratch[i % K], which=other)
             torch.cuda.synchronize()
             ta = time.perf_counter()
             for i in range(K):
