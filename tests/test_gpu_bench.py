@@ -43,3 +43,22 @@ def test_bench_flag_combinations(args, env):
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert 0.0 < d["price_mean"] < 0.1 and d["config"]["workload"].startswith("Q2b option_pricing")
     assert d["steps"] == int(args[args.index("--steps") + 1])
+
+
+def test_bench_two_rank_control_flow_rehearsal():
+    """N = 2 launched exactly as the driver does (torch.distributed.run, one process per rank), in rehearsal mode: both
+    ranks on the one visible GPU, all-reduce over gloo.  Not a measurement -- it pins the multi-rank control flow
+    (sharding by global id, bucketed all-reduce, MAX of the elapsed time over ranks, rank 0 prints ONE line)."""
+    e = dict(os.environ, HWMC_BENCH_REHEARSAL="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--spinup-ms", "50"],
+                       capture_output=True, text=True, timeout=400, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert CONTRACT_KEYS <= set(d) and d["n_gpus"] == 2 and "rehearsal" in d
+    assert d["config"]["effective_paths"] == 2 * 2 * d["config"]["pairs_per_gpu"]
+    # the two shards together price the option: mean of 3 runs of 2^22 samples each
+    assert abs(d["price_mean"] - 0.0252555) < 5e-4
