@@ -344,16 +344,19 @@ def main():
         value = (n_total / ms_per_step) / 1000.0
         steps_exec = int(round(5.0 * a.grid_steps / 10.0))
         info = e.device_info()
-        # Path-kernel duration: hipEvent pairs tight around each of the K launches, replayed in the timed region's
-        # alternation (untimed pass 1) -- the quantity rocprofv3's kernel-trace average reports; kiso is the same
-        # kernel alone on the chip (pass 2).  The event pair around the whole timed region gives the time the GPU
-        # actually spent per step, column pass and launch gaps included: the utilisation figures use that one.
+        # Path-kernel duration.  kiso: hipEvent pairs tight around each of K launches issued strictly one after another
+        # (untimed pass 2) = the kernel alone on the chip; rocprofv3's kernel-trace average for this command run with
+        # --streams 1 reports the same quantity (profiles/rNN_bench_streams1_kernel_stats.csv) and roofline.achieved
+        # uses it.  kavg: the same K launches replayed in the timed region's alternation over S streams (pass 1): two
+        # dispatches then share the chip, so each one lasts up to twice as long as it occupies the chip for; the
+        # comparable rocprofv3 figure for the default command is the union of the dispatch intervals per launch
+        # (profiles/rNN_pmc_summary.json, kernel_trace.chip_time_per_launch_us) against timed_region_ms_per_step.
         kavg = float(np.mean(kernel_ms))
         kiso = float(np.mean(kernel_ms_isolated))
         region_per_step = region_ms / K
         geo_blocks = min((n_pairs + (a.block or 512) - 1) // (a.block or 512), 1 << 20)   # one 256-thread workgroup per 256 pairs (csrc/hw_engine.hip geometry())
         algo_bytes = geo_blocks * 5 * 8 + 5 * 8            # partial rows written + the 5 sums (stateless Philox: no state traffic)
-        achieved = algo_bytes / (kavg * 1e-3) / 1e9
+        achieved = algo_bytes / (kiso * 1e-3) / 1e9
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
         if os.path.exists(pmc) and a.stepper == "superposed" and a.paths_log2 == 20 and a.grid_steps == 1000:
@@ -392,8 +395,10 @@ def main():
             "beta_mean": float(np.mean([r["beta"] for r in prices])),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "zbc_%s_kernel" % a.stepper, "kernel_ms_avg": kavg, "kernel_ms_min": float(np.min(kernel_ms)),
-                         "kernel_ms_isolated_avg": kiso, "timed_region_ms_per_step_hip_events": region_per_step,
+                         "kernel": "zbc_%s_kernel" % a.stepper, "kernel_ms_avg": kiso, "kernel_ms_min": float(np.min(kernel_ms_isolated)),
+                         "kernel_ms_avg_basis": "K launches back to back on one stream, hipEvent pair around each (matches rocprofv3 --stats of this command with --streams 1)",
+                         "kernel_ms_avg_overlapped_replay": kavg, "kernel_ms_isolated_avg": kiso,
+                         "timed_region_ms_per_step_hip_events": region_per_step,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "stateless Philox: the path kernel has ~0 algorithmic HBM traffic; the binding roof is VALU issue (see valu)"},
             "valu": {"bound": "valu-issue", "issue_cycles_per_wave_per_4_steps": cyc_per_block,
