@@ -339,7 +339,8 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
     if (std::is_same<REAL, float>::value && p.n_steps % 4 == 0 && stride % 2 == 0 && stride >= 4 && !c->curve_generic &&
         (1.0 - (double)(float)k.e) * std::sqrt((double)p.n_steps) >= 0.05) {
         const int64_t resident = (int64_t)c->prop.multiProcessorCount * 2048;
-        const int P = n_pairs >= 8 * resident ? 4 : n_pairs >= 4 * resident ? 2 : 1;   // keep >= 2 rounds of waves
+        int P = n_pairs >= 8 * resident ? 4 : n_pairs >= 4 * resident ? 2 : 1;   // keep >= 2 rounds of waves
+        if (const char* m = getenv("HWMC_CURVE_P")) { const int v = atoi(m); if (v == 1 || v == 2 || v == 4) P = v; }   // tools/curve_p_probe.py
         const Geometry g = geometry(c, n_pairs, P, true);
         int rc = ensure_partials(c, (size_t)g.grid * n_mat);
         if (rc) return rc;

@@ -1,0 +1,78 @@
+"""CPU guard on the shape of the hot loop: the gfx950 listing of the production ZBC kernel (hipcc cross-compiles here)
+must keep the instruction counts DESIGN.md section 5 and bench.py's VALU_MODEL quote -- a compiler or source change
+that adds wide multiplies, transcendentals, scratch or registers shows up here without a GPU."""
+import os
+import re
+import subprocess
+import sys
+from collections import Counter
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "monte-carlo-simulation-of-hull-white-model-and-sensitivities-computation_amd")
+
+
+@pytest.fixture(scope="module")
+def listing(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("asm") / "eng.s")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", out,
+                           os.path.join(PKG, "csrc", "hw_engine.hip")], stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _kernel(listing, pattern):
+    m = re.search(r"^(_ZN3hwk[^\n:]*%s[^\n:]*):[^\n]*\n(.*?)\.end_amdhsa_kernel" % re.escape(pattern), listing, re.S | re.M)
+    assert m, pattern
+    tail = listing[m.end():m.end() + 6000]
+    meta = {k: int(re.search(r"; %s: (\d+)" % k, tail).group(1)) for k in ("NumVgprs", "ScratchSize", "Occupancy")}
+    return m.group(2).split("\n"), meta
+
+
+def _hot_loops(lines):
+    labels = {}
+    for i, l in enumerate(lines):
+        mm = re.match(r"^(\.LBB\d+_\d+):", l.strip())
+        if mm:
+            labels[mm.group(1)] = i
+    spans = []
+    for i, l in enumerate(lines):
+        mm = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", l)
+        if mm and mm.group(1) in labels and labels[mm.group(1)] <= i:
+            spans.append((labels[mm.group(1)], i))
+    inner = [a for a in spans if not any(b != a and a[0] <= b[0] and b[1] <= a[1] for b in spans)]
+    out = []
+    for a, b in inner:
+        ins = [l.strip().split()[0] for l in lines[a:b + 1] if l.strip() and not l.strip().startswith((";", "."))]
+        c = Counter(ins)
+        if c["v_mad_u64_u32"] >= 10:
+            out.append(c)
+    return out
+
+
+def test_zbc_f32_hot_loop_keeps_its_instruction_budget(listing):
+    lines, meta = _kernel(listing, "zbc_superposed_kernelIfLi1ELi1E")
+    assert meta["ScratchSize"] == 0 and meta["NumVgprs"] <= 64 and meta["Occupancy"] == 8
+    loops = _hot_loops(lines)
+    trans = ("v_log_f32_e32", "v_sqrt_f32_e64", "v_sqrt_f32_e32", "v_sin_f32_e32", "v_cos_f32_e32")
+    best = min(loops, key=lambda c: (c["v_mad_u64_u32"], sum(v for k, v in c.items() if k.startswith("v_"))))
+    valu = sum(v for k, v in best.items() if k.startswith("v_"))
+    assert best["v_mad_u64_u32"] == 16                      # scalar round-2 multiply (UHI copy of the loop)
+    assert best["v_bitop3_b32"] == 14 and best["v_xor_b32_e32"] <= 4
+    assert sum(best[t] for t in trans) == 8 and best["v_cvt_f32_u32_e32"] == 4
+    assert valu <= 60, (valu, dict(best))                   # 59 today
+    # every copy of the blocked loop (with and without the uniform high word) stays within one multiply of it
+    assert all(c["v_mad_u64_u32"] <= 17 for c in loops)
+
+
+def test_other_kernels_have_no_scratch_and_full_occupancy(listing):
+    for pat in ("vega_pathwise_kernelIfLi1E", "zcb_curve_blocked_kernelILi1E", "zcb_curve_blocked_kernelILi2E",
+                "zbc_superposed_kernelIfLi2ELi1E", "zbc_reference_kernelILi0E"):
+        _, meta = _kernel(listing, pat)
+        assert meta["ScratchSize"] == 0 and meta["Occupancy"] == 8, (pat, meta)
+    _, meta = _kernel(listing, "zbc_superposed_kernelIfLi3ELi1E")      # 15 double accumulators: 7 waves per SIMD
+    assert meta["ScratchSize"] == 0 and meta["Occupancy"] >= 7, meta
+    # four pairs per thread carry 4 x (4 Philox words + y + W + live): 74 registers, 6 waves per SIMD -- measured
+    # faster than two pairs at 8 waves all the same (tools/curve_p_probe.py); it must not spill or drop further
+    _, meta = _kernel(listing, "zcb_curve_blocked_kernelILi4E")
+    assert meta["ScratchSize"] == 0 and meta["Occupancy"] >= 6 and meta["NumVgprs"] <= 80, meta
