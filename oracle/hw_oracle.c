@@ -11,9 +11,9 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
-
-#define ORA_CHUNK 512   /* pairs per partial sum: fixes the order of the floating-point additions */
 #endif
+
+#define ORA_CHUNK 512   /* pairs per partial sum: fixes the order of the floating-point additions (with or without OpenMP) */
 
 /* ======================================================================================== *
  *  Philox4x32-10  (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11;

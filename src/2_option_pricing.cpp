@@ -6,7 +6,7 @@
 // the reference defines (output.cuh:112-126) and analyze.py:299 reads but no reference code writes.
 #include "hw_app.hpp"
 
-static void theta_recovery(const hw_params& p, const std::vector<float>& f, int64_t n_paths)
+static bool theta_recovery(const hw_params& p, const std::vector<float>& f, int64_t n_paths)
 {
     const int n_mat = p.n_mat, stride = p.n_steps / (n_mat - 1);
     std::vector<float> rec(n_mat), orig(n_mat), Ts(n_mat);
@@ -31,6 +31,7 @@ static void theta_recovery(const hw_params& p, const std::vector<float>& f, int6
     }
     app::csv_comparison("data/theta_comparison.csv", Ts.data(), orig.data(), rec.data(), "T", "theta_original",
                         "theta_recovered", n_mat);
+    return ok;
 }
 
 static hw_zbc_request option_request(const app::Options& opt, int64_t n, uint64_t seed)
@@ -158,7 +159,7 @@ int main(int argc, char** argv)
     app::load_market(opt, p, &P, &f);
     fleet.set_market(P.data(), f.data());
 
-    theta_recovery(p, f, n);
+    const bool theta_ok = theta_recovery(p, f, n);
     const uint64_t t0 = (uint64_t)time(nullptr);
     const uint64_t seed = opt.have_seed ? opt.seed : t0 + 54321;                 // 2_option:128
     const double P0S2 = P[p.n_mat - 1];                                          // 2_option:492
@@ -169,7 +170,9 @@ int main(int argc, char** argv)
         validation(fleet, opt, n, opt.have_seed ? opt.seed + 1000003ull : t0 * 1000000ull, P0S2);   // 2_option:223
 
     if (FILE* s = app::summary_section("data/summary.txt", "Q2: THETA RECOVERY & OPTION PRICING")) {
-        fprintf(s, "  Theta recovery: SUCCESS (max error < 0.01)\n  ZBC option (CV): %.8f\n  Variance reduction: Control variate enabled\n", price);
+        // the reference writes "SUCCESS" here whatever the check said (2_option:505); this follows the check
+        fprintf(s, "  Theta recovery: %s\n  ZBC option (CV): %.8f\n  Variance reduction: Control variate enabled\n",
+                theta_ok ? "SUCCESS (max error < 0.01)" : "FAILED (max error >= 0.01)", price);
         fclose(s);
     }
     fleet.destroy();

@@ -36,28 +36,45 @@ static void kernel_report(app::Fleet& fleet)
     printf("  Theoretical occupancy:      %.1f%%\n\n", 100.0 * ki.blocks_per_cu * ki.block_size / 64 / 32.0);
 }
 
-// benchmark_block_sizes, 3_sens:277-371 (1 warm-up + 20 timed launches per size)
+// benchmark_block_sizes, 3_sens:277-371 (1 warm-up + 20 timed launches per size).  The reference sweeps
+// {128, 256, 512, 1024} threads per block; 64 (one wavefront) is added because it is the native unit here.
 static void block_size_sweep(app::Fleet& fleet, int64_t n, uint64_t seed)
 {
-    printf("\n---WORKGROUP SIZE SWEEP---\n\nBlock Size | Time (ms) | Throughput (M/s)\n-----------|-----------|-----------------\n");
+    hw_device_info di;
+    HW_CHECK(hw_get_device_info(fleet.ctx[0], &di));
+    printf("\n---BLOCK SIZE OPTIMIZATION SWEEP---\n\n");
+    printf("Testing different workgroup sizes to find optimal configuration.\n\n");
+    printf("Block Size | Grid Size | Time (ms) | Throughput (M/s) | Blocks/CU\n");
+    printf("-----------|-----------|-----------|------------------|----------\n");
     const int sizes[] = {64, 128, 256, 512, 1024};
+    const int n_sizes = (int)(sizeof sizes / sizeof sizes[0]);
+    float times[n_sizes];
     int best = 0;
     float best_ms = 1e30f;
-    for (int bs : sizes) {
+    const double K = (double)expf(-0.1f);
+    for (int i = 0; i < n_sizes; i++) {
+        const int bs = sizes[i];
         HW_CHECK(hw_set_launch(fleet.ctx[0], bs, 0, 0, 1));
         double out;
         float ms = 0.0f, total = 0.0f;
-        HW_CHECK(hw_vega_pathwise(fleet.ctx[0], n, seed, 0, kS1, kS2, (double)expf(-0.1f), 0, &out, &ms));
-        for (int j = 0; j < 20; j++) {
-            HW_CHECK(hw_vega_pathwise(fleet.ctx[0], n, seed, 0, kS1, kS2, (double)expf(-0.1f), 0, &out, &ms));
+        HW_CHECK(hw_vega_pathwise(fleet.ctx[0], n, seed, 0, kS1, kS2, K, 0, &out, &ms));          // warm-up, 3_sens:307-310
+        for (int j = 0; j < 20; j++) {                                                            // 3_sens:313-325
+            HW_CHECK(hw_vega_pathwise(fleet.ctx[0], n, seed, 0, kS1, kS2, K, 0, &out, &ms));
             total += ms;
         }
         const float avg = total / 20.0f;
-        printf("%10d | %9.3f | %16.2f\n", bs, avg, (n / avg) / 1000.0);
+        times[i] = avg;
+        const long long nb = (long long)((n + bs - 1) / bs);
+        printf("%10d | %9lld | %9.3f | %16.2f | %9.1f\n", bs, nb, avg, (n / avg) / 1000.0, (double)nb / di.compute_units);
         if (avg < best_ms) { best_ms = avg; best = bs; }
     }
-    printf("\nBest configuration: %d threads/workgroup (%.3f ms)\n", best, best_ms);
-    HW_CHECK(hw_set_launch(fleet.ctx[0], -1, 0, 0, 1));
+    printf("\n--- Analysis ---\nBest configuration: %d threads/block (%.3f ms)\n\nRelative Performance:\n", best, best_ms);
+    for (int i = 0; i < n_sizes; i++) {                                                           // 3_sens:349-359
+        const float rel = 100.0f * best_ms / times[i];
+        printf("  %4d threads/block: %5.1f%%%s%s\n", sizes[i], rel, sizes[i] == best ? " OPTIMAL" : "",
+               rel < 90.0f ? " too small, high overhead" : "");
+    }
+    HW_CHECK(hw_set_launch(fleet.ctx[0], -1, 0, 0, 1));                                           // back to the automatic choice
 }
 
 int main(int argc, char** argv)

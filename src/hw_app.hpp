@@ -51,9 +51,11 @@ struct Options {
     int64_t n() const { return (int64_t)1 << paths_log2; }
 };
 
-[[noreturn]] inline void die(const char* what)
+[[noreturn]] inline void die(const char* what, const char* text = nullptr)
 {
-    printf("HIP Error [%s]: %s\n", what, hw_last_error());      // check_cuda, common.cuh:114-120
+    // check_cuda, common.cuh:114-120.  hw_last_error() is per thread: a caller that ran the engine on a worker
+    // thread passes the text it captured there.
+    printf("HIP Error [%s]: %s\n", what, text ? text : hw_last_error());
     exit(1);
 }
 #define HW_CHECK(call) do { if ((call) != HW_OK) app::die(#call); } while (0)
@@ -262,14 +264,16 @@ struct Fleet {
         std::vector<double> part(5 * G, 0.0);
         std::vector<float> t(G, 0.0f);
         std::vector<int> rc(G, 0);
+        std::vector<std::string> err(G);
         const uint64_t base_off = r.path_offset;
         for_each_device(r.n_pairs, [&](int g, int64_t off, int64_t cnt) {
             hw_zbc_request q = r;
             q.n_pairs = cnt;
             q.path_offset = base_off + (uint64_t)off;
             rc[g] = hw_zbc_moments(ctx[g], &q, &part[5 * g], &t[g]);
+            if (rc[g] != HW_OK) err[g] = hw_last_error();          // thread-local: read it on the thread that failed
         });
-        for (size_t g = 0; g < G; g++) if (rc[g] != HW_OK) die("hw_zbc_moments");
+        for (size_t g = 0; g < G; g++) if (rc[g] != HW_OK) die("hw_zbc_moments", err[g].c_str());
         for (int k = 0; k < 5; k++) { out[k] = 0.0; for (size_t g = 0; g < G; g++) out[k] += part[5 * g + k]; }
         if (ms) *ms = *std::max_element(t.begin(), t.end());
     }
@@ -280,10 +284,12 @@ struct Fleet {
         std::vector<double> part((size_t)p.n_mat * G, 0.0);
         std::vector<float> t(G, 0.0f);
         std::vector<int> rc(G, 0);
+        std::vector<std::string> err(G);
         for_each_device(n, [&](int g, int64_t off, int64_t cnt) {
             rc[g] = hw_zcb_curve(ctx[g], cnt, seed, (uint64_t)off, sigma, &part[(size_t)p.n_mat * g], &t[g]);
+            if (rc[g] != HW_OK) err[g] = hw_last_error();
         });
-        for (size_t g = 0; g < G; g++) if (rc[g] != HW_OK) die("hw_zcb_curve");
+        for (size_t g = 0; g < G; g++) if (rc[g] != HW_OK) die("hw_zcb_curve", err[g].c_str());
         P_sum->assign(p.n_mat, 0.0);
         for (int j = 0; j < p.n_mat; j++) for (size_t g = 0; g < G; g++) (*P_sum)[j] += part[(size_t)p.n_mat * g + j];
         if (ms) *ms = *std::max_element(t.begin(), t.end());
@@ -295,11 +301,13 @@ struct Fleet {
         std::vector<double> part(G, 0.0);
         std::vector<float> t(G, 0.0f);
         std::vector<int> rc(G, 0);
+        std::vector<std::string> err(G);
         for_each_device(n, [&](int g, int64_t off, int64_t cnt) {
             rc[g] = hw_vega_pathwise(ctx[g], cnt, seed, (uint64_t)off, S1, S2, K, 0, &part[g], &t[g]);
+            if (rc[g] != HW_OK) err[g] = hw_last_error();
         });
         double total = 0.0;
-        for (size_t g = 0; g < G; g++) { if (rc[g] != HW_OK) die("hw_vega_pathwise"); total += part[g]; }
+        for (size_t g = 0; g < G; g++) { if (rc[g] != HW_OK) die("hw_vega_pathwise", err[g].c_str()); total += part[g]; }
         if (ms) *ms = *std::max_element(t.begin(), t.end());
         return total;
     }

@@ -72,6 +72,32 @@ def test_host_post_processing_matches_oracle(hwmc_mod, oracle_mod):
         assert re_[k] == pytest.approx(ro[k], rel=2e-5)       # float32 vs double post-processing
 
 
+@pytest.mark.parametrize("profile", ["head", "readme"])
+def test_recover_theta_equals_the_oracle_elementwise(hwmc_mod, oracle_mod, profile):
+    """hw_recover_theta (recover_theta + compute_derivative + theta_func: src/2_option_pricing.cu:14-35,
+    include/common.cuh:228-230, 250-258) beside the oracle's restatement, element by element, on the exact curve
+    and on a Monte Carlo curve (the oracle's own simulate_zcb at 2048 pairs).  Both are float32 host code calling
+    glibc's expf with contraction off, so the three arrays must be IDENTICAL, not merely close."""
+    p = hwmc_mod.default_params(profile)
+    o = oracle_mod.Oracle(profile)
+    _, f_exact = hwmc_mod.analytic_curve(p)
+    _, f_mc = o.average_and_forward(o.zcb_curve(2048, 11), 4096)
+    lib = C.CDLL(hwmc_mod.LIB_PATH)
+    fp = C.POINTER(C.c_float)
+    for f in (f_exact, f_mc):
+        rec, orig, Ts = (np.zeros(101, np.float32) for _ in range(3))
+        rc = lib.hw_recover_theta(C.byref(p), f.ctypes.data_as(fp), rec.ctypes.data_as(fp), orig.ctypes.data_as(fp),
+                                  Ts.ctypes.data_as(fp))
+        assert rc == 0
+        rec_o, orig_o, Ts_o = o.recover_theta(f)
+        np.testing.assert_array_equal(Ts, Ts_o)
+        np.testing.assert_array_equal(orig, orig_o)
+        np.testing.assert_array_equal(rec, rec_o)
+    # and the statistic the reference prints (2_option:49-67): max |rec - orig| over every 10th point
+    rec, orig, _ = o.recover_theta(f_exact)
+    assert float(np.abs(rec - orig)[::10].max()) < 0.01
+
+
 def test_no_gpu_gives_error_not_fallback(hwmc_mod):
     """Without a GPU hw_create must fail loudly (HW_E_HIP); with one, it must succeed."""
     import torch

@@ -14,6 +14,13 @@ CONTRACT_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per
                  "vs_baseline", "dtype", "data", "config", "roofline"}
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _bench(*args, env=None):
     e = dict(os.environ)
     e.update(env or {})
@@ -51,7 +58,7 @@ def test_bench_two_rank_control_flow_rehearsal():
     (sharding by global id, bucketed all-reduce, MAX of the elapsed time over ranks, rank 0 prints ONE line)."""
     e = dict(os.environ, HWMC_BENCH_REHEARSAL="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(ROOT, "bench.py"),
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--steps", "3", "--warmup", "1", "--spinup-ms", "50"],
                        capture_output=True, text=True, timeout=400, env=e, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]

@@ -62,6 +62,7 @@ def test_three_executables_file_contract(built, tmp_path):
     boot = open(d / "data" / "zbc_bootstrap_optimal.csv").read().splitlines()
     assert boot[0] == "run,price_adjusted,price_raw,beta_optimal,correlation" and len(boot) == 21
     assert "Variance Reduction:" in open(d / "data" / "zbc_statistics_optimal.txt").read()
+    assert "Theta recovery: SUCCESS (max error < 0.01)" in open(d / "data" / "summary.txt").read()
 
     # q3: "n" to the sweep, "y" to the validation (3_sens:725-749)
     r3 = _run("q3", d, "--paths-log2", "18", "--seed", "5", "--theta-profile", "readme", stdin="n\ny\n")
@@ -75,6 +76,31 @@ def test_three_executables_file_contract(built, tmp_path):
     assert os.path.exists(d / "data" / "vega_statistics.txt")
     summary = open(d / "data" / "summary.txt").read()
     assert "Q1: ZERO-COUPON BOND PRICING" in summary and "Q2: THETA RECOVERY & OPTION PRICING" in summary and "Q3: SENSITIVITY ANALYSIS" in summary
+
+
+def test_q3_block_size_sweep_path(built, tmp_path):
+    """q3 answering "y" to the first prompt runs benchmark_block_sizes (src/3_sensitivity_analysis.cu:277-371): one
+    warm-up + 20 timed launches of the pathwise-Vega kernel per workgroup size.  The reference's four sizes must each
+    give a row (plus 64, one wavefront), every row with a positive time, and the run must go on to the FD section and
+    leave the launch geometry on automatic (the Vega printed afterwards by the validation equals a default run's)."""
+    _run("q1", tmp_path, "--paths-log2", "16", "--seed", "21", "--theta-profile", "readme", "--spinup-ms", "0")
+    r = _run("q3", tmp_path, "--paths-log2", "16", "--seed", "5", "--theta-profile", "readme", "--spinup-ms", "0", stdin="y\nn\n")
+    out = r.stdout
+    assert "---BLOCK SIZE OPTIMIZATION SWEEP---" in out and "Best configuration:" in out and "Relative Performance:" in out
+    rows = {}
+    for line in out.splitlines():
+        parts = [x.strip() for x in line.split("|")]
+        if len(parts) == 5 and parts[0].isdigit():
+            rows[int(parts[0])] = (int(parts[1]), float(parts[2]), float(parts[3]))
+    assert set(rows) == {64, 128, 256, 512, 1024}                       # reference: {128, 256, 512, 1024} (3_sens:286)
+    for bs, (grid, ms, thr) in rows.items():
+        assert grid == ((1 << 16) + bs - 1) // bs and ms > 0 and thr > 0
+    assert out.index("Best configuration:") < out.index("FINITE DIFFERENCE APPROXIMATION")
+    q3 = json.load(open(tmp_path / "data" / "q3_results.json"))
+    r0 = _run("q3", tmp_path, "--paths-log2", "16", "--seed", "5", "--theta-profile", "readme", "--spinup-ms", "0", "--no")
+    q3n = json.load(open(tmp_path / "data" / "q3_results.json"))
+    assert q3["results"] == q3n["results"]                               # the sweep changed no result
+    assert "OPTIMAL" in out and "ERROR" not in r0.stdout
 
 
 def test_exact_market_and_reference_stepper_flags(built, tmp_path):
