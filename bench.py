@@ -1,34 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the Hull-White Monte Carlo hot path on MI355X.
 
-Metric (BASELINE.json): M paths/sec of the ZBC option kernel (2^20 antithetic pairs per GPU,
-1000-step grid over T=10 -> 500 executed steps to S1=5, optimal-beta control variate),
-throughput defined exactly as the reference does: (2*N_PATHS / ms) / 1000
-(src/2_option_pricing.cu:198).  One "step" = one pricing call = one launch of the path kernel
-over the whole batch + the reduction of its five moment sums; the K timed steps use K different
-seeds, i.e. they ARE the reference's 20-run statistical validation (2_option:210-468), from
-which the 95 % CI width of the metric is computed.
+Metric (BASELINE.json): M paths/sec of the ZBC option kernel (1000-step grid over T=10 -> 500 executed steps to S1=5,
+optimal-beta control variate), throughput defined exactly as the reference does: (2*N_PATHS / ms) / 1000
+(src/2_option_pricing.cu:198).  One "step" = one pricing call = one launch of the path kernel over the whole batch +
+the reduction of its five moment sums (+ for N > 1 ONE all-reduce of those five doubles over RCCL); the K timed steps
+use K different seeds, i.e. they ARE the reference's 20-run statistical validation (2_option:210-468), from which
+the 95 % CI width of the metric is computed.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Pipelining: the K steps are independent pricing batches, so each GPU alternates them over S contexts (S HIP
-streams, --streams, default 2): the ~15 us a 2^20-pair launch loses to launch latency and fill/drain
-(tools/size_scan.py) is filled by the next batch's waves.  Every batch is still one full launch; the sums are
-bit-identical to the single-stream run (tools/overlap_probe.py) and the JSON line also carries the
-single-stream figure ("serial").
+Workload.  N = 1: BASELINE configs[1], 2^20 antithetic pairs per step.  N > 1: BASELINE configs[3], STRONG scaling of a
+2^24-pair pricing call (--total-log2): rank g prices the global pairs [g*2^24/N, (g+1)*2^24/N) of every step, and the five
+sums of every step are all-reduced over RCCL -- one collective per pricing call (--allreduce-every 1, the default),
+issued from a stream of its own that waits on an event of the step's compute stream, so no compute stream ever waits
+for RCCL.  (--scaling weak keeps 2^20 pairs per GPU; --allreduce-every 0 sends ONE message for all K steps.)
+Because the sample set depends only on (seed, global pair id), the reduced sums do not depend on N.
 
-N > 1: one process per GPU; rank g prices global pairs [g*n, (g+1)*n) of an N*n-pair run (weak
-scaling), and the five moment sums of every step are all-reduced over RCCL inside the timed region:
-by default as ONE message of 5*K doubles after the last launch (--allreduce-every B sends one message
-per B steps from a stream of its own; measured with a one-rank communicator that costs 3-6 % because
-RCCL's stream lands on one of the two hardware queues the launches alternate over).  Rank 0 prints ONE
-JSON line.
+Timing.  EXACTLY K steps are timed between barrier + torch.cuda.synchronize() on both sides, MAX over ranks; that
+region is repeated --regions times (fresh barriers each time) and `value` is the MEDIAN region, with the spread beside
+it: at 2^20 pairs a region lasts only K * 0.18 ms.
+
+Pipelining.  The K steps are independent pricing batches, so each GPU alternates them over S contexts (S HIP streams,
+--streams, default 2): the ~13 us a launch spends outside the kernel (dispatch, end-of-kernel release) and the drain of
+the last waves are covered by the next batch.  Every batch is still one full launch; the sums are bit-identical to the
+single-stream run, and the line carries the strictly serial rate ("serial") and the kernel alone on the chip
+("kernel_Mpaths_per_sec_isolated_launch", which is what rocprofv3 --stats reports for --streams 1) next to `value`.
 """
 import argparse
+import glob
 import json
 import os
+import re
 import sys
 import time
 
@@ -36,19 +41,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # VALU issue model of the path kernel's inner loop, per Philox block = 4 time steps of one pair
-# (instruction counts from the gfx950 disassembly -- tools/loop_census.py --, issue cycles per wave64 instruction per SIMD
-#  measured by tools/valu_rates.hip on MI355X: full rate 2, half rate 4, quarter rate 8).
+# (instruction counts from the gfx950 disassembly -- tools/loop_census.py, pinned by tests/test_kernel_census.py --,
+#  issue cycles per wave64 instruction per SIMD measured by tools/valu_rates.hip on MI355X: full rate 2, half rate 4,
+#  quarter rate 8).
 VALU_MODEL = {
     "superposed": {"full": 30, "half": 21, "quarter": 8},   # 14 bitop3,4 xor,4 fmamk,2 mul,4 fma/fmac,2 add | 16 mad_u64,4 cvt,1 pk_fma | 2 log,2 sqrt,2 sin,2 cos
     "reference": {"full": 64, "half": 20, "quarter": 8},    # + per step: sG mul, 2 add, 2 fma, 2 add, 2 mul/fma pairs on two legs
-    # double stepper: per-step fmac_f64 + add_f64 on converted normals:
-    # 14 bitop3,4 xor,4 fmamk,4 mul | 16 mad_u64,4 cvt_u32,4 cvt_f64,4 fmac_f64,4 add_f64 | 8 transcendentals
-    "superposed_f64": {"full": 26, "half": 32, "quarter": 8},
+    # double stepper, (y, W) block form: 14 bitop3,4 xor,4 fmamk,3 mul,2 add,2 fma,1 fmac | 16 mad_u64,4 cvt_u32,3 cvt_f64,2 fmac_f64,1 add_f64 | 8 transcendentals
+    "superposed_f64": {"full": 30, "half": 26, "quarter": 8},
 }
-# Issue costs measured on MI355X at 8 waves/SIMD (tools/valu_rates.hip, tools/valu_patterns.hip; profiles/):
-# "full-rate" ops sustain one per 2.3 cycles (two waves issue side by side; one wave alone: 4.7),
-# v_mad_u64_u32 4.45, v_cvt_f32_u32 4.24, transcendentals 8.1 -- each class measured alone; in the mixed loop part of
-# v_cvt hides under single-rate ops (tools/coissue_probe.hip) and the kernel runs at the nominal 2/4/8 model.
 MEASURED_ISSUE = {"full": 2.3, "half": 4.4, "quarter": 8.1}
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 V100_PUBLISHED_MPATHS = 1064.0  # BASELINE.md section 1 (reference README.md:44,162; one V100)
@@ -59,7 +60,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--paths-log2", type=int, default=20, help="antithetic pairs per GPU (log2)")
+    ap.add_argument("--regions", type=int, default=7, help="how many times the timed K-step region is repeated (median reported)")
+    ap.add_argument("--paths-log2", type=int, default=20, help="antithetic pairs per step: per GPU for N = 1 and for --scaling weak (log2)")
+    ap.add_argument("--total-log2", type=int, default=24, help="N > 1, --scaling strong: pairs per step over ALL GPUs (log2); BASELINE configs[3] = 24")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--grid-steps", type=int, default=1000)
     ap.add_argument("--stepper", default="superposed", choices=["superposed", "reference"])
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
@@ -67,11 +71,11 @@ def parse():
     ap.add_argument("--block", type=int, default=0, help="threads per workgroup (0 = engine default)")
     ap.add_argument("--streams", type=int, default=2,
                     help="contexts (HIP streams) per GPU the independent steps alternate over; 1 = strictly serial")
-    ap.add_argument("--allreduce-every", type=int, default=0,
-                    help="N > 1: all-reduce the sums of this many consecutive steps as one message; 0 (default) = ONE "
-                         "all-reduce of all K steps' sums after the last launch, inside the timed region -- the K steps "
-                         "are the reference's 20-run validation, whose statistics need the sums only at the end")
+    ap.add_argument("--allreduce-every", type=int, default=1,
+                    help="N > 1: all-reduce the sums of this many consecutive steps as one message (default 1: one collective "
+                         "per pricing call); 0 = ONE all-reduce of all K steps' sums after the last launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (other stepper, 20-run launch, curve kernel, 2^24 reference)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--spinup-ms", type=float, default=400.0,
                     help="untimed launches before the W warm-up steps so the timed region runs at the "
@@ -80,8 +84,9 @@ def parse():
 
 
 def cpu_baseline(P, f, profile, grid_steps, seconds):
-    """The oracle's OpenMP loop (same stepper, same Philox stream) on this host's cores, on a
-    bounded sample of the same workload; throughput is per path so it compares directly."""
+    """The oracle's OpenMP loops (same steppers, same Philox stream) on this host's cores, on bounded samples of the
+    same workloads; throughput is per path so it compares directly.  `value` = the ZBC loop (the metric's kernel);
+    `q1_curve` = BASELINE configs[0], the Q1 curve loop at 2^20 pairs x 1000 steps (src/1_bond_pricing.cu:60-71,110)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import hw_oracle
     o = hw_oracle.Oracle(profile, n_steps=grid_steps)
@@ -97,11 +102,69 @@ def cpu_baseline(P, f, profile, grid_steps, seconds):
     t0 = time.perf_counter()
     o.zbc_moments(P, f, n1, 3, n_threads=1)
     dt1 = time.perf_counter() - t0
-    return {"value": 2 * n / dt / 1e6, "unit": "M paths/s", "cores": cores, "cores_how": how, "kind": "port",
-            "sample": "%d antithetic pairs x %d executed steps, OpenMP %d threads, %.1f s (oracle/hw_oracle.c)"
-                      % (n, o.steps_to(5.0), cores, dt),
-            "single_thread_value": 2 * n1 / dt1 / 1e6,
-            "single_thread_sample": "%d pairs, %.1f s" % (n1, dt1)}
+    out = {"value": 2 * n / dt / 1e6, "unit": "M paths/s", "cores": cores, "cores_how": how, "kind": "port",
+           "sample": "%d antithetic pairs x %d executed steps, OpenMP %d threads, %.1f s (oracle/hw_oracle.c)"
+                     % (n, o.steps_to(5.0), cores, dt),
+           "single_thread_value": 2 * n1 / dt1 / 1e6,
+           "single_thread_sample": "%d pairs, %.1f s" % (n1, dt1)}
+    # configs[0]: Q1 bond_pricing, 2^20 pairs x 1000 steps x 100 maturities on the host cores -- the whole
+    # configuration when it fits the time budget (it does from ~8 cores up), else a sample scaled per path
+    o1 = hw_oracle.Oracle(profile, n_steps=1000)
+    t0 = time.perf_counter()
+    o1.zcb_curve(1 << 12, 1, n_threads=cores)
+    r1 = (1 << 12) / max(time.perf_counter() - t0, 1e-6)
+    nq = int(min(1 << 20, max(1 << 12, r1 * max(seconds, 4.0))))
+    t0 = time.perf_counter()
+    o1.zcb_curve(nq, 2, n_threads=cores)
+    dq = time.perf_counter() - t0
+    nq1 = max(nq // (4 * cores), 1 << 10)
+    t0 = time.perf_counter()
+    o1.zcb_curve(nq1, 3, n_threads=1)
+    dq1 = time.perf_counter() - t0
+    out["q1_curve"] = {"config": "BASELINE configs[0]: Q1 bond_pricing, 2^20 pairs x 1000 steps, antithetic, 100 maturities, CPU OpenMP loop",
+                       "value": 2 * nq / dq / 1e6, "unit": "M paths/s", "cores": cores, "ms": dq * 1e3,
+                       "sample": "%d antithetic pairs x 1000 steps (%s), OpenMP %d threads, %.1f s"
+                                 % (nq, "the full configuration" if nq == 1 << 20 else "scaled per path", cores, dq),
+                       "single_thread_value": 2 * nq1 / dq1 / 1e6, "single_thread_sample": "%d pairs, %.1f s" % (nq1, dq1),
+                       "reference_metric": "throughput = (2*N_PATHS/ms)/1000, src/1_bond_pricing.cu:110"}
+    return out
+
+
+def newest_pmc_summary(config_is_default):
+    """HBM traffic per launch from the newest committed rocprofv3 --pmc summary (profiles/rNN_pmc_summary.json), or None:
+    the counters are collected by separate profiler runs of this command (tools/profile_round.sh), never in-process."""
+    if not config_is_default:
+        return None, None
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")):
+        m = re.match(r"r(\d+)_pmc_summary\.json$", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    if best is None:
+        return None, None
+    try:
+        with open(best[1]) as fh:
+            d = json.load(fh)
+        return d["hbm_traffic_bytes_per_launch"]["corrected_bytes"], {
+            "file": "profiles/" + os.path.basename(best[1]), "kernel": d.get("kernel"), "command": d.get("command"),
+            "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (separate runs); FETCH_SIZE x2 on gfx950"}
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
+def union_ms(spans):
+    """Total length of the union of [start, end] intervals."""
+    total, cur_a, cur_b = 0.0, None, None
+    for a, b in sorted(spans):
+        if cur_b is None or a > cur_b:
+            if cur_b is not None:
+                total += cur_b - cur_a
+            cur_a, cur_b = a, b
+        else:
+            cur_b = max(cur_b, b)
+    if cur_b is not None:
+        total += cur_b - cur_a
+    return total
 
 
 def main():
@@ -141,10 +204,13 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    cdev = "cpu" if rehearsal else dev                 # where the small control tensors of the collectives live
 
     import numpy as np
     import hwmc
-    n_pairs = 1 << a.paths_log2
+    # ---- workload -------------------------------------------------------------------------------------------
+    n_total = hwmc.parallel.pricing_workload(world, a.scaling, a.paths_log2, a.total_log2)
+    offset, shard_n = hwmc.parallel.shard(n_total, rank, world)    # rank g owns global pairs [offset, offset + shard_n)
     p = hwmc.default_params(a.profile, n_steps=a.grid_steps, precision=a.precision)
     P, f = hwmc.analytic_curve(p)                      # synthetic market input (exact curve)
     S = max(1, min(a.streams, 8))
@@ -157,103 +223,105 @@ def main():
         engines.append(eng)
     e = engines[0]
     stepper = hwmc.HW_STEPPER_SUPERPOSED if a.stepper == "superposed" else hwmc.HW_STEPPER_REFERENCE
-    K, W = a.steps, a.warmup
+    K, W, R = a.steps, a.warmup, max(1, a.regions)
     out = torch.zeros((K + W, 5), dtype=torch.float64, device=dev)
-    # Explicit side streams: step i runs on streams[i % S], made torch's CURRENT stream while it is issued, so
-    # the kernels go to it through the C ABI, torch's events time it and RCCL orders that step's all-reduce
-    # after it.  (A NULL handle would mean "the context's own stream" to the C ABI.)
-    # HIP multiplexes its streams onto a few hardware queues (4 here) and two streams that share a queue
-    # serialise (tools/queue_map_probe.py: which streams share one depends on the creation history of the whole
-    # process).  So take 8 candidate streams and keep, greedily, those that run the workload fastest together.
-    cands = [torch.cuda.Stream(device=dev) for _ in range(8 if S > 1 else 1)]
-    assert all(st.cuda_stream != 0 for st in cands)
-    pairing = None
-    if S > 1:
-        cal_out = torch.zeros((8, 5), dtype=torch.float64, device=dev)
-
-        def trial(chosen):
-            best = float("inf")
-            for _ in range(3):
-                torch.cuda.synchronize()
-                tc = time.perf_counter()
-                for j in range(8):
-                    engines[j % len(chosen)].enqueue_ZBC(cal_out[j].data_ptr(), n_pairs, 7 + j, stepper=stepper,
-                                                         stream=cands[chosen[j % len(chosen)]].cuda_stream)
-                torch.cuda.synchronize()
-                best = min(best, (time.perf_counter() - tc) * 1e3 / 8)
-            return best
-
-        for _ in range(40):                                 # clocks up before comparing anything
-            trial([0])
-        chosen, table = [0], {}
-        while len(chosen) < S:
-            scores = {j: trial(chosen + [j]) for j in range(len(cands)) if j not in chosen}
-            table[len(chosen) + 1] = {str(j): round(v, 4) for j, v in scores.items()}
-            chosen.append(min(scores, key=scores.get))
-        streams = [cands[j] for j in chosen]
-        pairing = {"candidates": len(cands), "chosen": chosen, "ms_per_step_when_added": table,
-                   "ms_per_step_single_stream": round(trial([0]), 4)}
-    else:
-        streams = cands
-    torch.cuda.synchronize()
-    torch.cuda.set_stream(streams[0])
-    # weak scaling: an (N * n_pairs)-pair run, rank g owns the contiguous shard hwmc.parallel.shard gives it
-    offset, shard_n = hwmc.parallel.shard(n_pairs * world, rank, world)
-    assert shard_n == n_pairs
-
-    class _Done:
-        def wait(self):
-            return None
-
-    def enqueue(i, seed, dst, n_streams=S, which=stepper):
-        k = i % n_streams
-        engines[k].enqueue_ZBC(dst.data_ptr(), n_pairs, seed, path_offset=offset, stepper=which,
-                               stream=streams[k].cuda_stream)
-        return k
-
-    # Collectives: the sums of B consecutive steps (--allreduce-every, rows of `out` are contiguous) go out as ONE
-    # all-reduce of 5*B doubles.  It is issued from a stream of its own that waits on an event of every compute
-    # stream, so no compute stream ever waits for another one or for RCCL.
-    B = max(1, a.allreduce_every) if a.allreduce_every > 0 else (K + W)
-    comm_stream = torch.cuda.Stream(device=dev)
-    pending = {"first": None}
-
-    def flush(i_last):
-        i0, pending["first"] = pending["first"], None
-        if i0 is None or not dist_on:
-            return None
-        if rehearsal:                                                   # host round trip, synchronous
-            torch.cuda.synchronize()
-            tmp = out[i0:i_last + 1].cpu()
-            dist.all_reduce(tmp)
-            out[i0:i_last + 1].copy_(tmp)
-            return _Done()
-        for st in streams:
-            comm_stream.wait_stream(st)                                 # event record + wait: the compute streams run on
-        with torch.cuda.stream(comm_stream):
-            return hwmc.parallel.allreduce_sums(out[i0:i_last + 1], async_op=True, force=True)
-
-    def step(i, seed, last=False):
-        enqueue(i, seed, out[i])
-        if pending["first"] is None:
-            pending["first"] = i
-        if last or i - pending["first"] + 1 >= B:
-            return flush(i)
-        return None
+    B = max(1, a.allreduce_every) if a.allreduce_every > 0 else K
 
     def fence():
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The communicator (and the stream torch's RCCL backend runs its kernels on) must exist BEFORE the compute streams
+    # are chosen: the choice below measures the workload INCLUDING the per-step all-reduce.
+    if dist_on:
+        warm = torch.zeros(5, dtype=torch.float64, device=cdev)
+        dist.all_reduce(warm)
+        fence()
+    comm_stream = torch.cuda.Stream(device=dev)
+
+    class _Done:
+        def wait(self):
+            return None
+
+    def all_reduce_rows(i0, i1, on_streams):
+        """One all-reduce of out[i0:i1+1] (contiguous), ordered after the compute streams that produced the rows."""
+        if rehearsal:                                                   # host round trip, synchronous
+            torch.cuda.synchronize()
+            tmp = out[i0:i1 + 1].cpu()
+            dist.all_reduce(tmp)
+            out[i0:i1 + 1].copy_(tmp)
+            return _Done()
+        for st in on_streams:
+            comm_stream.wait_stream(st)                                 # event record + wait: the compute streams run on
+        with torch.cuda.stream(comm_stream):
+            return hwmc.parallel.allreduce_sums(out[i0:i1 + 1], async_op=True, force=True)
+
+    # Explicit side streams: step i runs on streams[i % S], handed to the C ABI as a raw hipStream_t.
+    # HIP multiplexes its streams onto a few hardware queues (4 here) and two streams that share a queue
+    # serialise (tools/queue_map_probe.py: which streams share one depends on the creation history of the whole
+    # process).  So take 8 candidate streams and keep, greedily, those that run the workload fastest together --
+    # with the per-step all-reduce in the loop when there is one, so that the queue RCCL's stream landed on counts.
+    cands = [torch.cuda.Stream(device=dev) for _ in range(8 if S > 1 else 1)]
+    assert all(st.cuda_stream != 0 for st in cands)
+    pairing = None
+    if S > 1:
+        cal_out = out                                                   # rows 0..7 (K + W >= 8 not required: modulo)
+        with_ar = dist_on and not rehearsal and a.allreduce_every == 1
+
+        def trial(chosen, with_ar=with_ar):
+            best = float("inf")
+            for _ in range(3):
+                torch.cuda.synchronize()
+                tc = time.perf_counter()
+                works = []
+                for j in range(8):
+                    row = j % (K + W)
+                    k = j % len(chosen)
+                    engines[k].enqueue_ZBC(cal_out[row].data_ptr(), shard_n, 7 + j, path_offset=offset, stepper=stepper,
+                                           stream=cands[chosen[k]].cuda_stream)
+                    if with_ar:
+                        works.append(all_reduce_rows(row, row, [cands[chosen[k]]]))
+                for w in works:
+                    w.wait()
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - tc) * 1e3 / 8)
+            return best
+
+        t_cal = time.perf_counter()
+        while (time.perf_counter() - t_cal) * 1e3 < min(a.spinup_ms, 150.0):   # clocks up before comparing anything
+            trial([0], with_ar=False)                                   # (a time-bounded loop must not contain collectives)
+        chosen, table = [0], {}
+        while len(chosen) < S:
+            # (every rank runs the same NUMBER of trials, hence of collectives; which stream wins is local to the rank)
+            scores = {j: trial(chosen + [j]) for j in range(len(cands)) if j not in chosen}
+            table[len(chosen) + 1] = {str(j): round(v, 4) for j, v in scores.items()}
+            chosen.append(min(scores, key=scores.get))
+        streams = [cands[j] for j in chosen]
+        pairing = {"candidates": len(cands), "chosen": chosen, "ms_per_step_when_added": table,
+                   "ms_per_step_single_stream": round(trial([0]), 4), "all_reduce_in_the_trial": with_ar}
+    else:
+        streams = cands
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(streams[0])
+
+    def enqueue(i, seed, dst, n_streams=S, which=stepper, n=None, off=None, eng_list=None):
+        k = i % n_streams
+        (eng_list or engines)[k].enqueue_ZBC(dst.data_ptr(), shard_n if n is None else n, seed,
+                                             path_offset=offset if off is None else off, stepper=which,
+                                             stream=streams[k].cuda_stream)
+        return k
+
+    reducer = hwmc.parallel.StepReducer(a.allreduce_every, K + W,
+                                        lambda i0, i1, ks: all_reduce_rows(i0, i1, [streams[j] for j in ks]))
+
+    def step(i, seed, last=False):
+        k = enqueue(i, seed, out[i])
+        return reducer.after_step(i, producer=k, last=last) if dist_on else None
+
     def join_streams():                                                 # streams[0] waits for the others
         for st in streams[1:]:
             streams[0].wait_stream(st)
-
-    if dist_on:                                                        # build the communicator outside any timed region
-        warm = torch.zeros(5, dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(warm)
-        fence()
 
     t_spin = time.perf_counter()
     while (time.perf_counter() - t_spin) * 1e3 < a.spinup_ms:      # untimed: bring the clocks up
@@ -265,41 +333,65 @@ def main():
         if w is not None:
             w.wait()
     fence()
-    # One HIP event pair brackets the K timed launches: recorded on streams[0] before the first launch and,
-    # after streams[0] has been made to wait for the other streams, behind the last one.  Per-launch event
-    # pairs are taken in a second, untimed pass below.
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    works = []
-    t0 = time.perf_counter()
-    ev0.record(streams[0])
-    for i in range(K):
-        works.append(step(W + i, 1234 + 12345 * i, last=(i == K - 1)))   # seeds as 2_option:229: base + run*12345
-    join_streams()
-    ev1.record(streams[0])
-    for w in works:
-        if w is not None:
-            w.wait()
-    torch.cuda.synchronize()                               # every local launch AND every all-reduce has completed, i.e.
-    elapsed = time.perf_counter() - t0                     # every rank has contributed all its K steps; MAX over ranks below
-    if dist_on:
-        dist.barrier()
-        torch.cuda.synchronize()
-    region_ms = ev0.elapsed_time(ev1)
+
+    # ---- the timed regions: EXACTLY K steps each, barrier + synchronize on both sides -----------------------------
+    # One HIP event pair brackets the K launches of a region: recorded on streams[0] before the first launch and, after
+    # streams[0] has been made to wait for the other streams, behind the last one.
+    elapsed_regions, region_ms_events = [], []
+    for _ in range(R):
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        works = []
+        fence()
+        t0 = time.perf_counter()
+        ev0.record(streams[0])
+        for i in range(K):
+            works.append(step(W + i, 1234 + 12345 * i, last=(i == K - 1)))   # seeds as 2_option:229: base + run*12345
+        join_streams()
+        ev1.record(streams[0])
+        for w in works:
+            if w is not None:
+                w.wait()
+        torch.cuda.synchronize()                           # every local launch AND every all-reduce has completed, i.e.
+        elapsed_regions.append(time.perf_counter() - t0)   # every rank has contributed all its K steps; MAX over ranks below
+        fence()
+        region_ms_events.append(ev0.elapsed_time(ev1))
     sums = out[W:].cpu().numpy()                           # the K all-reduced moment vectors of the timed steps
-    scratch = torch.zeros((K, 5), dtype=torch.float64, device=dev)
-    # untimed pass 1: the same K launches in the same alternation with a hipEvent pair tight around every path
-    # kernel -- the per-launch durations rocprofv3's kernel trace reports for the timed region (with S > 1
-    # two launches share the chip for part of their life, so each one lasts longer than it would alone)
+    if dist_on:                                            # MAX over ranks, region by region (one collective)
+        t = torch.tensor(elapsed_regions, dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_regions = [float(x) for x in t.cpu()]
+    elapsed = float(np.median(elapsed_regions))
+
+    # ---- untimed side measurements ---------------------------------------------------------------------------------
+    scratch = torch.zeros((max(K, 8), 5), dtype=torch.float64, device=dev)
+
+    def respin(ms=60.0):
+        """Host-side bookkeeping between the passes (reading events back, Python) leaves the chip idle for milliseconds and
+        its clock starts to drop; every measurement pass below is preceded by a short untimed burst of the same launches."""
+        ts_ = time.perf_counter()
+        while (time.perf_counter() - ts_) * 1e3 < ms:
+            for j in range(8):
+                enqueue(j, 7, scratch[j % K])
+            torch.cuda.synchronize()
+
+    # pass 1: the same K launches in the same alternation with a hipEvent pair tight around every path kernel: the union of
+    # those dispatch intervals / K is the time the path kernel occupied the chip per step of the (replayed) timed region
+    respin()
     for eng in engines:
         eng.profile_enable(K)
     for i in range(K):
         enqueue(i, 1234 + 12345 * i, scratch[i])
     torch.cuda.synchronize()
+    spans = []
+    for eng in engines:
+        st_ms, en_ms = eng.profile_spans(ref=engines[0])
+        spans += list(zip(st_ms.tolist(), en_ms.tolist()))
     kernel_ms = np.concatenate([eng.profile_read(K) for eng in engines])
-    assert kernel_ms.size == K
-    # untimed pass 2: the same K launches strictly one after another on ONE stream: isolated kernel durations
-    # and the wall-clock rate without pipelining
+    assert kernel_ms.size == K and len(spans) == K
+    chip_ms_per_step = union_ms(spans) / K
+    # pass 2: the same K launches strictly one after another on ONE stream: isolated kernel durations ...
+    respin()
     e.profile_enable(K)
     for i in range(K):
         enqueue(i, 1234 + 12345 * i, scratch[i], n_streams=1)
@@ -307,18 +399,61 @@ def main():
     kernel_ms_isolated = e.profile_read(K)
     for eng in engines:
         eng.profile_enable(0)                              # event pairs off: they cost queue bubbles
-    torch.cuda.synchronize()
-    ts = time.perf_counter()
-    for i in range(K):
-        enqueue(i, 1234 + 12345 * i, scratch[i], n_streams=1)
-    torch.cuda.synchronize()
-    serial_ms = (time.perf_counter() - ts) * 1e3 / K
-    assert world > 1 or np.array_equal(scratch.cpu().numpy(), sums), "the stream count changed the sums"
-    clock_mhz = e.profile_clock_mhz() if a.stepper == "superposed" else None
-    # For the record, the OTHER stepper on the same workload (untimed w.r.t. the headline; N = 1 only): the
-    # reference's per-step arithmetic verbatim vs the superposed recursion, so both numbers sit in one line.
-    alt = None
+    # ... and the wall-clock rate without pipelining and without event pairs (median of the same number of regions)
+    serial_regions = []
+    respin()
+    for _ in range(R):
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for i in range(K):
+            enqueue(i, 1234 + 12345 * i, scratch[i], n_streams=1)
+        torch.cuda.synchronize()
+        serial_regions.append((time.perf_counter() - ts) * 1e3 / K)
+    serial_ms = float(np.median(serial_regions))
     if world == 1:
+        assert np.array_equal(scratch[:K].cpu().numpy(), sums), "the stream count changed the sums"
+    clock_mhz = e.profile_clock_mhz() if a.stepper == "superposed" else None
+    geo = e.launch_geometry("zbc" if a.stepper == "superposed" else "zbc_ref", shard_n)
+
+    # N > 1: one pricing call end to end, strictly serial -- launch, all-reduce, host sees the result -- i.e. the latency
+    # of a single sharded pricing call (what a caller of hw_comm_zbc_moments / bin/q2 --gpus N waits for)
+    single_call_ms = None
+    allreduce_alone_ms = None
+    if dist_on:
+        fence()
+        tt = []
+        for i in range(min(K, 10)):
+            dist.barrier()
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            enqueue(0, 1234 + 12345 * i, out[0], n_streams=1)
+            w = all_reduce_rows(0, 0, [streams[0]])
+            w.wait()
+            torch.cuda.synchronize()
+            tt.append((time.perf_counter() - tc) * 1e3)
+        tsc = torch.tensor([float(np.median(tt))], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tsc, op=dist.ReduceOp.MAX)
+        single_call_ms = float(tsc.item())
+        tt = []
+        for _ in range(10):                                # the collective alone (5 doubles), host-synchronous
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            w = all_reduce_rows(1, 1, [])
+            w.wait()
+            torch.cuda.synchronize()
+            tt.append((time.perf_counter() - tc) * 1e3)
+        allreduce_alone_ms = float(np.median(tt))
+        fence()
+    per_rank_kernel_ms = None
+    if dist_on:
+        mine = torch.tensor([float(np.mean(kernel_ms_isolated))], dtype=torch.float64, device=cdev)
+        allk = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allk, mine)
+        per_rank_kernel_ms = [float(x.item()) for x in allk]
+
+    extras = {}
+    if world == 1 and not a.no_extras:
+        # the OTHER stepper on the same workload: the reference's per-step arithmetic verbatim vs the superposed recursion
         other = hwmc.HW_STEPPER_REFERENCE if a.stepper == "superposed" else hwmc.HW_STEPPER_SUPERPOSED
         if not (other == hwmc.HW_STEPPER_REFERENCE and a.precision != "f32"):
             for i in range(3):
@@ -329,76 +464,132 @@ def main():
                 enqueue(i, 1234 + 12345 * i, scratch[i], which=other)
             torch.cuda.synchronize()
             alt_ms = (time.perf_counter() - ta) * 1e3 / K
-            alt = {"stepper": "reference" if other == hwmc.HW_STEPPER_REFERENCE else "superposed",
-                   "ms_per_step": alt_ms, "value": (2 * n_pairs / alt_ms) / 1000.0, "unit": "M paths/s"}
-    if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+            extras["other_stepper"] = {"stepper": "reference" if other == hwmc.HW_STEPPER_REFERENCE else "superposed",
+                                       "ms_per_step": alt_ms, "value": (2 * shard_n / alt_ms) / 1000.0, "unit": "M paths/s"}
+        if a.stepper == "superposed":
+            # the 20-run validation as ONE launch (hw_zbc_moments_runs): 20 x n pairs in a single grid, no pipelining needed
+            # to cover the launch overhead and the drain -- the non-pipelined way to run the reference's 20-run harness
+            ms20 = []
+            for _ in range(5):
+                _, ms = e.simulate_ZBC_runs(shard_n, 1234, n_runs=20, seed_stride=12345, return_ms=True)
+                ms20.append(ms)
+            m20 = float(np.median(ms20))
+            extras["runs20_single_launch"] = {"n_runs": 20, "pairs_per_run": shard_n, "ms": m20, "value": (20 * 2 * shard_n / m20) / 1000.0,
+                                              "unit": "M paths/s", "note": "path kernel + column pass of hw_zbc_moments_runs, hipEvent pair, median of 5"}
+        # the Q1 curve kernel at BASELINE configs[0]'s size (2^20 pairs x 1000 steps x 100 maturities), beside cpu_baseline.q1_curve
+        pc = hwmc.default_params(a.profile, n_steps=1000, precision=a.precision)
+        with hwmc.HullWhiteEngine(pc, device=local_rank) as ec:
+            msq = []
+            for j in range(12):
+                ec.profile_enable(1)
+                ec.simulate_zcb(1 << 20, 1234 + j)
+                msq.append(float(ec.profile_read(1)[0]))
+            mq = float(np.median(msq[2:]))
+            extras["q1_curve_gpu"] = {"pairs": 1 << 20, "grid_steps": 1000, "maturities": 100, "kernel_ms": mq,
+                                      "value": (2 * (1 << 20) / mq) / 1000.0, "unit": "M paths/s",
+                                      "vs_v100_391": ((2 * (1 << 20) / mq) / 1000.0) / 391.0}
+        # strong-scaling reference: the N > 1 workload (2^total_log2 pairs per step) on this ONE GPU, same pipelining
+        nref = 1 << a.total_log2
+        if a.scaling == "strong" and nref != shard_n and a.stepper == "superposed":
+            kk = 6
+            for i in range(2):
+                enqueue(i, 5, scratch[i], n=nref, off=0)
+            torch.cuda.synchronize()
+            tr = time.perf_counter()
+            for i in range(kk):
+                enqueue(i, 1234 + 12345 * i, scratch[i], n=nref, off=0)
+            torch.cuda.synchronize()
+            ref_ms = (time.perf_counter() - tr) * 1e3 / kk
+            tr = time.perf_counter()
+            for i in range(kk):
+                enqueue(i, 1234 + 12345 * i, scratch[i], n=nref, off=0, n_streams=1)
+            torch.cuda.synchronize()
+            ref_serial_ms = (time.perf_counter() - tr) * 1e3 / kk
+            extras["strong_scaling_reference"] = {
+                "pairs_per_step": nref, "n_gpus": 1, "ms_per_step": ref_ms, "value": (2 * nref / ref_ms) / 1000.0,
+                "serial_ms_per_step": ref_serial_ms, "unit": "M paths/s",
+                "note": "the workload bench.py --gpus N > 1 shards (BASELINE configs[3]) run whole on one GPU: divide an N-GPU line's "
+                        "ms_per_step into this one's for the strong-scaling factor"}
 
     if rank == 0:
-        n_total = 2 * n_pairs * world
-        prices = [hwmc.cv_price(s, n_total, float(P[-1])) for s in sums]
-        st = hwmc.run_statistics([r["price"] for r in prices])
+        n_eff = 2 * n_total
+        prices = [hwmc.cv_price(s, n_eff, float(P[-1])) for s in sums]
+        st = hwmc.run_statistics([r["price"] for r in prices]) if K > 1 else {"mean": prices[0]["price"], "ci95_width": None}
         ms_per_step = elapsed * 1e3 / K
-        value = (n_total / ms_per_step) / 1000.0
+        value = (n_eff / ms_per_step) / 1000.0
+        vals = sorted((n_eff / (x * 1e3 / K)) / 1000.0 for x in elapsed_regions)
         steps_exec = int(round(5.0 * a.grid_steps / 10.0))
         info = e.device_info()
-        # Path-kernel duration.  kiso: hipEvent pairs tight around each of K launches issued strictly one after another
-        # (untimed pass 2) = the kernel alone on the chip; rocprofv3's kernel-trace average for this command run with
-        # --streams 1 reports the same quantity (profiles/rNN_bench_streams1_kernel_stats.csv) and roofline.achieved
-        # uses it.  kavg: the same K launches replayed in the timed region's alternation over S streams (pass 1): two
-        # dispatches then share the chip, so each one lasts up to twice as long as it occupies the chip for; the
-        # comparable rocprofv3 figure for the default command is the union of the dispatch intervals per launch
-        # (profiles/rNN_pmc_summary.json, kernel_trace.chip_time_per_launch_us) against timed_region_ms_per_step.
+        # Path-kernel durations.  kiso: hipEvent pairs tight around each of K launches issued strictly one after another =
+        # the kernel alone on the chip; rocprofv3's kernel-trace average for this command run with --streams 1 reports the
+        # same quantity (profiles/rNN_bench_streams1_kernel_stats.csv) and roofline.achieved uses it.
         kavg = float(np.mean(kernel_ms))
         kiso = float(np.mean(kernel_ms_isolated))
-        region_per_step = region_ms / K
-        geo_blocks = min((n_pairs + (a.block or 512) - 1) // (a.block or 512), 1 << 20)   # one 256-thread workgroup per 256 pairs (csrc/hw_engine.hip geometry())
-        algo_bytes = geo_blocks * 5 * 8 + 5 * 8            # partial rows written + the 5 sums (stateless Philox: no state traffic)
+        region_per_step = float(np.median(region_ms_events)) / K
+        algo_bytes = geo["partial_bytes"] + 5 * 8         # partial rows written + the 5 sums (stateless Philox: no state traffic)
         achieved = algo_bytes / (kiso * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pmc) and a.stepper == "superposed" and a.paths_log2 == 20 and a.grid_steps == 1000:
-            with open(pmc) as fh:
-                traffic = json.load(fh)["hbm_traffic_bytes_per_launch"]["corrected_bytes"]
-            traffic_src = "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH_SIZE x2 on gfx950)"
+        default_cfg = (a.stepper == "superposed" and shard_n == 1 << 20 and a.grid_steps == 1000 and a.precision == "f32" and not a.block)
+        traffic, traffic_src = newest_pmc_summary(default_cfg)
         vm = VALU_MODEL["superposed_f64" if (a.stepper == "superposed" and a.precision == "f64") else a.stepper]
         cyc_per_block = 2 * vm["full"] + 4 * vm["half"] + 8 * vm["quarter"]
-        waves = (n_pairs + 63) // 64
+        waves = (shard_n + 63) // 64
         simd_cycles = waves * (steps_exec / 4.0) * cyc_per_block
         simd_hz = info["compute_units"] * 4 * info["clock_mhz"] * 1e6
         valu_frac = simd_cycles / (simd_hz * region_per_step * 1e-3)        # the chip over the timed region
         valu_frac_iso = simd_cycles / (simd_hz * kiso * 1e-3)               # one launch alone on the chip
         achieved_cyc = region_per_step * 1e-3 * (clock_mhz or info["clock_mhz"]) * 1e6 * info["compute_units"] * 4 / (waves * steps_exec / 4.0)
+        if world == 1:
+            workload = ("Q2b option_pricing (BASELINE configs[1]): 2^%d antithetic pairs x %d-step grid (%d executed to S1=5), "
+                        "optimal-beta control variate, 1 x MI355X" % (a.paths_log2, a.grid_steps, steps_exec))
+        elif a.scaling == "strong":
+            workload = ("Q2b option_pricing sharded (BASELINE configs[3]): 2^%d antithetic pairs per pricing call x %d-step grid (%d executed), "
+                        "sharded by global pair id over %d x MI355X, RCCL all-reduce of the 5 moment sums" % (a.total_log2, a.grid_steps, steps_exec, world))
+        else:
+            workload = ("Q2b option_pricing, weak scaling: 2^%d antithetic pairs per GPU x %d-step grid (%d executed), %d x MI355X, "
+                        "RCCL all-reduce of the 5 moment sums" % (a.paths_log2, a.grid_steps, steps_exec, world))
         line = {
             "metric": "M paths/sec (ZBC option, 1000 steps)", "value": round(value, 2), "unit": "M paths/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 5),
-            "higher_is_better": True, "scaling": "weak",
+            "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": round(value / V100_PUBLISHED_MPATHS, 3),
             "baseline": {"value": V100_PUBLISHED_MPATHS, "unit": "M paths/s", "hardware": "1x Tesla V100",
                          "source": "reference README.md:44,162 (single un-warmed launch)"},
             "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": "Q2b option_pricing: 2^%d antithetic pairs per GPU x %d-step grid (%d executed to S1=5), "
-                                   "optimal-beta control variate, %d x MI355X" % (a.paths_log2, a.grid_steps, steps_exec, world),
-                       "pairs_per_gpu": n_pairs, "effective_paths": n_total, "grid_steps": a.grid_steps,
+            "value_spread": {"timed_regions": R, "steps_per_region": K, "min": round(vals[0], 2), "median": round(value, 2),
+                             "max": round(vals[-1], 2), "region_ms": [round(x * 1e3, 4) for x in elapsed_regions],
+                             "note": "`value` is the median region; every region times exactly K steps between barrier + synchronize"},
+            "config": {"workload": workload,
+                       "pairs_per_step": n_total, "pairs_per_gpu": shard_n, "effective_paths": n_eff, "grid_steps": a.grid_steps,
                        "steps_executed": steps_exec, "stepper": a.stepper, "theta_profile": a.profile,
                        "rng": "Philox4x32-10 (rocRAND layout), stateless, subsequence = global pair id",
-                       "parallelism": ("paths sharded by global id; the 5 f64 moment sums of every step all-reduced over RCCL, %d steps per message" % B)
+                       "parallelism": ("paths sharded by global pair id; the 5 f64 moment sums all-reduced over RCCL, %s"
+                                       % ("one collective per pricing call" if B == 1 else "%d steps per message" % B))
                                       if world > 1 else "single GPU",
+                       "allreduce_every": a.allreduce_every if dist_on else None,
                        "streams_per_gpu": S, "stream_selection": pairing,
                        "pipelining": ("the K independent steps alternate over %d contexts/streams per GPU; every step is one full launch" % S)
-                                     if S > 1 else "none: steps run strictly one after another"},
-            "thread_steps_per_sec": n_pairs * world * steps_exec / (ms_per_step * 1e-3),
+                                     if S > 1 else "none: steps run strictly one after another",
+                       "n1_note": "N = 1 runs BASELINE configs[1] (2^20 pairs); N > 1 runs configs[3] (2^%d pairs in total, strong scaling): "
+                                  "see strong_scaling_reference for the same total on one GPU" % a.total_log2},
+            "thread_steps_per_sec": n_total * steps_exec / (ms_per_step * 1e-3),
             "price_mean": st["mean"], "ci95_width": st["ci95_width"], "ci95_halfwidth_single_run": prices[0]["ci95_halfwidth"],
             "beta_mean": float(np.mean([r["beta"] for r in prices])),
+            "sums_step0": [float(x) for x in sums[0]],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "zbc_%s_kernel" % a.stepper, "kernel_ms_avg": kiso, "kernel_ms_min": float(np.min(kernel_ms_isolated)),
                          "kernel_ms_avg_basis": "K launches back to back on one stream, hipEvent pair around each (matches rocprofv3 --stats of this command with --streams 1)",
-                         "kernel_ms_avg_overlapped_replay": kavg, "kernel_ms_isolated_avg": kiso,
+                         "kernel_ms_avg_overlapped_replay": kavg,
+                         "kernel_ms_per_step_in_timed_region": region_per_step,
+                         "kernel_ms_per_step_basis": "ONE hipEvent pair around the K launches of the timed region (recorded before the first launch and, "
+                                                     "once streams[0] waits for the other streams, behind the last), / K, median region: the chip time a step "
+                                                     "took inside the timed region (path kernel + column pass); it must not exceed ms_per_step",
                          "timed_region_ms_per_step_hip_events": region_per_step,
-                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "kernel_ms_per_step_replay_with_event_pairs": chip_ms_per_step,
+                         "kernel_ms_per_step_replay_basis": "union of the K path-kernel dispatch intervals (a hipEvent pair around EVERY launch, common clock) of an "
+                                                            "untimed replay of the same alternation, / K; the event pairs themselves cost queue bubbles, so this "
+                                                            "replay runs slower than the timed region",
+                         "algorithmic_bytes_per_launch": algo_bytes, "launch_geometry": geo,
                          "note": "stateless Philox: the path kernel has ~0 algorithmic HBM traffic; the binding roof is VALU issue (see valu)"},
             "valu": {"bound": "valu-issue", "model": "serial issue: 2 / 4 / 8 cycles per single-rate / multiply-convert-f64 / transcendental wave64 instruction per SIMD",
                      "issue_cycles_per_wave_per_4_steps": cyc_per_block, "instr_per_4_steps": vm,
@@ -410,12 +601,21 @@ def main():
                      "note": "fractions compare the model's cycles with the chip time per step of the timed region (isolated: with one "
                              "launch alone on the chip); they can pass 1 because part of v_cvt_f32_u32 hides under single-rate ops "
                              "(profiles: coissue probe).  Single-class issue rates measured alone: %s cycles." % MEASURED_ISSUE},
-            "kernel_Mpaths_per_sec_isolated_launch": (2 * n_pairs / kiso) / 1000.0,
-            "serial": {"streams_per_gpu": 1, "ms_per_step": serial_ms, "value": (2 * n_pairs / serial_ms) / 1000.0,
-                       "unit": "M paths/s per GPU", "note": "same K launches strictly one after another on one stream, no all-reduce"},
-            "other_stepper": alt,
+            "kernel_Mpaths_per_sec_isolated_launch": (2 * shard_n / kiso) / 1000.0,
+            "serial": {"streams_per_gpu": 1, "ms_per_step": serial_ms, "value": (2 * shard_n / serial_ms) / 1000.0,
+                       "vs_baseline": (2 * shard_n / serial_ms) / 1000.0 / V100_PUBLISHED_MPATHS,
+                       "unit": "M paths/s per GPU", "note": "same K launches strictly one after another on one stream, no all-reduce; median of %d regions" % R},
             "device": info["name"],
         }
+        line.update(extras)
+        if dist_on:
+            line["multi_gpu"] = {"all_reduce": "5 f64 per pricing call" if B == 1 else "5 f64 x %d steps per message" % B,
+                                 "single_call_ms": single_call_ms,
+                                 "single_call_value": (n_eff / single_call_ms) / 1000.0 if single_call_ms else None,
+                                 "single_call_note": "one sharded pricing call end to end, strictly serial: launch -> all-reduce -> host synchronises (MAX over ranks)",
+                                 "all_reduce_alone_ms": allreduce_alone_ms,
+                                 "per_rank_kernel_ms": per_rank_kernel_ms,
+                                 "end_to_end_ms_per_step": ms_per_step}
         if rehearsal:
             line["rehearsal"] = "gloo, all ranks on device 0 -- control-flow check only, not a measurement"
         assert 0.0 < st["mean"] < 0.1 and all(np.isfinite(s).all() for s in sums), "implausible reduced sums"

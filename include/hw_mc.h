@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HW_ABI_VERSION 1
+#define HW_ABI_VERSION 2
 
 /* error codes */
 #define HW_OK            0
@@ -131,7 +131,15 @@ int  hw_set_launch(hw_ctx* ctx, int32_t block_size, int32_t max_blocks_per_cu, i
 int  hw_zbc_moments(hw_ctx* ctx, const hw_zbc_request* req, double out[5], float* kernel_ms);
 
 /* Same, enqueue only: results land in d_out (DEVICE pointer, 5 doubles) in stream order on
- * `stream` (a hipStream_t; NULL = the context's stream).  No host synchronisation. */
+ * `stream` (a hipStream_t; NULL = the context's stream).
+ * Streams and the context's workspaces.  Every launch of a context reuses the context's device workspaces
+ * (partial sums, tables), in stream order.  Calls on ONE stream pipeline freely.  A call on a different stream
+ * than the context's previous call is still correct: its stream is first made to wait, on the device, for
+ * everything the context has enqueued before (an event, no host wait) -- so two streams never overlap through
+ * one context.  For overlap use one context per stream (bench.py does).  Host blocking: none in the steady
+ * state; the call may block the HOST only when it has to grow the workspace (hipMalloc, first call at a larger
+ * size -- the outgrown buffer is released later, never under running kernels) or when four table uploads of
+ * this context are still in flight (pinned staging ring). */
 int  hw_zbc_moments_async(hw_ctx* ctx, const hw_zbc_request* req, double* d_out, void* stream);
 
 /* n_runs independent pricings in ONE launch: run k uses seed + k*seed_stride on the same pairs
@@ -189,6 +197,15 @@ int  hw_debug_raw(hw_ctx* ctx, uint64_t seed, uint64_t subseq, int32_t n_blocks,
  * and writes the elapsed milliseconds (returns the count via *n_out) and disables profiling. */
 int  hw_profile_enable(hw_ctx* ctx, int32_t max_launches);
 int  hw_profile_read(hw_ctx* ctx, float* ms, int32_t cap, int32_t* n_out);
+/* Start and end of every profiled launch of `ctx`, in milliseconds after the FIRST profiled launch of `ref` started
+ * (ref may be ctx; both on the same device): lets a benchmark lay the launches of several streams on one time axis
+ * (union of the dispatch intervals).  Call before hw_profile_read, which resets the recording. */
+int  hw_profile_spans(hw_ctx* ctx, hw_ctx* ref, float* start_ms, float* end_ms, int32_t cap, int32_t* n_out);
+/* The launch geometry the engine would use for `n_units` pairs/paths of kernel "zbc" | "zbc_ref" | "vega" | "zcb" |
+ * "zcb_blocked": threads per workgroup, workgroups, iterations per thread, and the bytes of partial sums the path
+ * kernel writes (the algorithmic HBM traffic of a launch).  Any output pointer may be NULL. */
+int  hw_get_launch_geometry(hw_ctx* ctx, const char* kernel, int64_t n_units, int32_t* block, int32_t* grid,
+                            int32_t* iters, int64_t* partial_bytes);
 /* Shader clock (MHz) the chip held during the last profiled superposed-ZBC launch, from an
  * in-kernel s_memtime / s_memrealtime probe in workgroup 0 (read after the launch completed). */
 int  hw_profile_clock(hw_ctx* ctx, double* shader_mhz);

@@ -78,6 +78,9 @@ SIGNATURES = {
     "hw_profile_enable": (C.c_int, [_CTX, C.c_int32]),
     "hw_profile_read": (C.c_int, [_CTX, _FP, C.c_int32, C.POINTER(C.c_int32)]),
     "hw_profile_clock": (C.c_int, [_CTX, _DP]),
+    "hw_profile_spans": (C.c_int, [_CTX, _CTX, _FP, _FP, C.c_int32, C.POINTER(C.c_int32)]),
+    "hw_get_launch_geometry": (C.c_int, [_CTX, C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "hw_get_kernel_info": (C.c_int, [_CTX, C.c_char_p, C.POINTER(HwKernelInfo)]),
     "hw_comm_create": (C.c_int, [C.c_int32, C.POINTER(_CTX), C.POINTER(C.c_void_p)]),
     "hw_comm_destroy": (None, [C.c_void_p]),
@@ -115,7 +118,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
-    if lib.hw_abi_version() != 1:
+    if lib.hw_abi_version() != 2:
         raise ImportError("libhw_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -10,13 +10,18 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hw_mc.h"
@@ -94,20 +99,84 @@ struct hw_ctx {
     // optional per-launch event pairs around the path kernel (hw_profile_enable)
     std::vector<hipEvent_t> prof_ev;
     int prof_used = 0, prof_cap = 0;
+    // The workspaces above are reused by every launch of the context, in stream order.  A call that arrives on a
+    // DIFFERENT stream than the previous one first makes its stream wait (on the device) for everything the context
+    // has enqueued so far: use_stream().
+    hipStream_t last_stream = nullptr;
+    bool have_last_stream = false;
+    hipEvent_t ev_switch = nullptr;
+    // workspaces outgrown while launches may still be reading them: freed at the next host synchronisation / destroy
+    std::vector<void*> retired;
+    // pinned staging ring for the small host->device uploads (drift table of the REFERENCE stepper, per-maturity
+    // scales of the curve): a slot is reused only after the copy that last read it has completed (its event)
+    struct Stage { void* h = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };
+    Stage stage[4];
+    int stage_next = 0;
+    // what d_drift / d_scale currently hold (skip the upload when a launch asks for the same table again)
+    double drift_key_sigma = -1.0; int drift_key_mode = -1, drift_key_n = -1; bool drift_valid = false;
+    double scale_key_sigma = -1.0; bool scale_valid = false;
 };
 
 namespace {
 
 constexpr int kOutCap = 1024;
 
+// Grow the partial-sum workspace.  Launches already enqueued may still be writing the old buffer, and hipFree
+// synchronises the whole device, so the old buffer is only RETIRED here; free_retired() releases it once the host
+// has synchronised with the context's work (the synchronous entry points, hw_destroy).
 int ensure_partials(hw_ctx* c, size_t doubles)
 {
     if (doubles <= c->partials_cap) return HW_OK;
-    if (c->d_partials) HIP_TRY(hipFree(c->d_partials));
-    c->d_partials = nullptr;
-    c->partials_cap = 0;
-    HIP_TRY(hipMalloc(&c->d_partials, doubles * sizeof(double)));
-    c->partials_cap = doubles;
+    const size_t want = std::max(doubles, c->partials_cap + c->partials_cap / 2);
+    double* fresh = nullptr;
+    HIP_TRY(hipMalloc(&fresh, want * sizeof(double)));
+    if (c->d_partials) c->retired.push_back(c->d_partials);
+    c->d_partials = fresh;
+    c->partials_cap = want;
+    return HW_OK;
+}
+
+void free_retired(hw_ctx* c)          // caller guarantees that nothing enqueued before this call is still running
+{
+    for (void* p : c->retired) (void)hipFree(p);
+    c->retired.clear();
+}
+
+// Stream-order guard of the per-context workspaces (d_partials, d_ticket, d_drift, d_scale): see hw_ctx.
+int use_stream(hw_ctx* c, hipStream_t st)
+{
+    if (c->have_last_stream && c->last_stream != st) {
+        HIP_TRY(hipEventRecord(c->ev_switch, c->last_stream));       // everything enqueued so far on the old stream
+        HIP_TRY(hipStreamWaitEvent(st, c->ev_switch, 0));
+    }
+    c->last_stream = st;
+    c->have_last_stream = true;
+    return HW_OK;
+}
+
+// Copy `bytes` from host memory to `dst` on stream `st` through the pinned ring: the caller's buffer may be a
+// stack/vector temporary (it is copied into pinned memory before this returns) and the call never blocks on the
+// device unless all four slots still have copies in flight.
+int stage_upload(hw_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st)
+{
+    hw_ctx::Stage& sl = c->stage[c->stage_next];
+    c->stage_next = (c->stage_next + 1) % 4;
+    if (sl.pending) {
+        HIP_TRY(hipEventSynchronize(sl.ev));
+        sl.pending = false;
+    }
+    if (sl.cap < bytes) {
+        if (sl.h) HIP_TRY(hipHostFree(sl.h));
+        sl.h = nullptr;
+        sl.cap = 0;
+        HIP_TRY(hipHostMalloc(&sl.h, std::max<size_t>(bytes, 4096), hipHostMallocDefault));
+        sl.cap = std::max<size_t>(bytes, 4096);
+    }
+    if (!sl.ev) HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    memcpy(sl.h, src, bytes);
+    HIP_TRY(hipMemcpyAsync(dst, sl.h, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(sl.ev, st));
+    sl.pending = true;
     return HW_OK;
 }
 
@@ -227,7 +296,9 @@ int launch_zbc_superposed(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, co
     const Geometry g = geometry(c, r->n_pairs, ilp);
     if ((int64_t)g.grid * n_runs > ((int64_t)1 << 22)) return fail(HW_E_INVALID, "n_runs x workgroups per run exceeds 2^22");
     const int total_grid = g.grid * n_runs;
-    int rc = ensure_partials(c, (size_t)total_grid * 5 * NSCEN);
+    int rc = use_stream(c, st);
+    if (rc) return rc;
+    rc = ensure_partials(c, (size_t)total_grid * 5 * NSCEN);
     if (rc) return rc;
     hwk::ZbcArgs<REAL, NSCEN> a{};
     a.n_pairs = r->n_pairs;
@@ -255,11 +326,19 @@ int launch_zbc_reference(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, con
                          double* d_out, hipStream_t st)
 {
     const Geometry g = geometry(c, r->n_pairs, 1);
-    int rc = ensure_partials(c, (size_t)g.grid * 5);
+    int rc = use_stream(c, st);
     if (rc) return rc;
-    std::vector<float> tab(n_steps_S1);
-    for (int i = 0; i < n_steps_S1; i++) tab[i] = (float)s.drift[i];
-    HIP_TRY(hipMemcpyAsync(c->d_drift, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    rc = ensure_partials(c, (size_t)g.grid * 5);
+    if (rc) return rc;
+    if (!(c->drift_valid && c->drift_key_sigma == s.sigma && c->drift_key_mode == s.drift_mode && c->drift_key_n == n_steps_S1)) {
+        std::vector<float> tab(n_steps_S1);
+        for (int i = 0; i < n_steps_S1; i++) tab[i] = (float)s.drift[i];
+        c->drift_valid = false;
+        rc = stage_upload(c, c->d_drift, tab.data(), tab.size() * sizeof(float), st);
+        if (rc) return rc;
+        c->drift_key_sigma = s.sigma; c->drift_key_mode = s.drift_mode; c->drift_key_n = n_steps_S1;
+        c->drift_valid = true;
+    }
     hwk::ZbcRefArgs a{};
     a.n_pairs = r->n_pairs;
     a.seed = r->seed;
@@ -324,13 +403,23 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
     const hw_params& p = c->p;
     if (!(sigma > 0.0)) sigma = p.sigma;
     const int n_mat = p.n_mat, stride = p.n_steps / (n_mat - 1);
+    {
+        const int rcu = use_stream(c, st);
+        if (rcu) return rcu;
+    }
     const hw::StepConstants k = hw::step_constants(p, sigma);
-    std::vector<double> drift, m, cI;
-    hw::drift_tables(p, sigma, &drift, nullptr);          // recompute_market_data, 3_sens:449-455
-    hw::mean_path(p.r0, k.e, k.dt, drift, p.n_steps, &m, &cI);
-    std::vector<double> scale(n_mat, 1.0);
-    for (int j = 1; j < n_mat; j++) scale[j] = std::exp(-cI[(size_t)j * stride]);
-    HIP_TRY(hipMemcpyAsync(c->d_scale, scale.data(), n_mat * sizeof(double), hipMemcpyHostToDevice, st));
+    if (!(c->scale_valid && c->scale_key_sigma == sigma)) {
+        std::vector<double> drift, m, cI;
+        hw::drift_tables(p, sigma, &drift, nullptr);          // recompute_market_data, 3_sens:449-455
+        hw::mean_path(p.r0, k.e, k.dt, drift, p.n_steps, &m, &cI);
+        std::vector<double> scale(n_mat, 1.0);
+        for (int j = 1; j < n_mat; j++) scale[j] = std::exp(-cI[(size_t)j * stride]);
+        c->scale_valid = false;
+        int rcs = stage_upload(c, c->d_scale, scale.data(), n_mat * sizeof(double), st);
+        if (rcs) return rcs;
+        c->scale_key_sigma = sigma;
+        c->scale_valid = true;
+    }
 
     // float, whole Philox blocks, maturities on half-block boundaries: the blocked kernel, P pairs per thread
     // (P = 4 / 2 once the batch still fills the chip's 8 waves per SIMD twice over: measured, one round of fat
@@ -357,7 +446,7 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
         a.e2 = a.e * a.e;
         a.c1 = (float)(cz * inv);
         a.c2 = (float)(cz * ((double)a.e * inv + 0.5));
-        const size_t lds = (size_t)(g.block / 64) * n_mat * sizeof(double);
+        const size_t lds = (size_t)(g.block / 64) * hwk::maturity_groups(n_mat) * hwk::kWave * sizeof(double);
         if (lds > 64 * 1024)
             return fail(HW_E_INVALID, "n_mat = %d needs %zu B of LDS per workgroup at block size %d (limit 65536): use a smaller block", n_mat, lds, g.block);
         prof_mark(c, st, 0);
@@ -384,7 +473,7 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
     a.iters = g.iters;
     a.e = (REAL)k.e;
     a.cz = (REAL)(k.dt * k.sig_st * kLog2e * hwk::kBmScale);
-    const size_t lds = (size_t)(g.block / 64) * n_mat * sizeof(double);
+    const size_t lds = (size_t)(g.block / 64) * hwk::maturity_groups(n_mat) * hwk::kWave * sizeof(double);
     if (lds > 64 * 1024)
         return fail(HW_E_INVALID, "n_mat = %d needs %zu B of LDS per workgroup at block size %d (limit 65536): use a smaller block", n_mat, lds, g.block);
     prof_mark(c, st, 0);
@@ -419,6 +508,8 @@ int launch_vega(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset,
     const Geometry g = geometry(c, n_paths, ilp);
     if ((int64_t)g.grid * n_runs > ((int64_t)1 << 22)) return fail(HW_E_INVALID, "n_runs x workgroups per run exceeds 2^22");
     const int total_grid = g.grid * n_runs;
+    rc = use_stream(c, st);
+    if (rc) return rc;
     rc = ensure_partials(c, (size_t)total_grid);
     if (rc) return rc;
     hwk::VegaArgs<REAL> a{};
@@ -462,6 +553,7 @@ int timed_sync(hw_ctx* c, int n_out, double* out, float* kernel_ms, F enqueue)
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipMemcpyAsync(out, c->d_out, n_out * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    free_retired(c);       // the context's stream has waited for every earlier launch of the context (use_stream)
     if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, c->ev0, c->ev1));
     return HW_OK;
 }
@@ -532,6 +624,7 @@ int hw_create(const hw_params* p, int device, hw_ctx** out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_switch, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&c->d_out, kOutCap * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&c->d_scale, (size_t)p->n_mat * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&c->d_drift, (size_t)p->n_steps * sizeof(float));
@@ -557,6 +650,14 @@ void hw_destroy(hw_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->have_last_stream && c->last_stream != c->stream) (void)hipStreamSynchronize(c->last_stream);
+    free_retired(c);
+    for (hw_ctx::Stage& sl : c->stage) {
+        if (sl.h) (void)hipHostFree(sl.h);
+        if (sl.ev) (void)hipEventDestroy(sl.ev);
+    }
+    if (c->ev_switch) (void)hipEventDestroy(c->ev_switch);
     if (c->d_partials) (void)hipFree(c->d_partials);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_scale) (void)hipFree(c->d_scale);
@@ -759,7 +860,12 @@ int hw_sample_paths(hw_ctx* c, int32_t n, uint64_t seed, uint64_t path_offset, f
     const size_t bytes = (size_t)n * (p.n_steps + 1) * sizeof(float);
     float* d_paths = nullptr;
     HIP_TRY(hipMalloc(&d_paths, bytes));
-    hipError_t e = hipMemcpyAsync(c->d_drift, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    c->drift_valid = false;                                               // d_drift now holds the full base table
+    hipError_t e = hipSuccess;
+    if (use_stream(c, c->stream) != HW_OK || stage_upload(c, c->d_drift, tab.data(), tab.size() * sizeof(float), c->stream) != HW_OK) {
+        (void)hipFree(d_paths);
+        return HW_E_HIP;
+    }
     if (e == hipSuccess) {
         hipLaunchKernelGGL(hwk::sample_paths_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, d_paths,
                            (const float*)c->d_drift, n, p.n_steps, seed, path_offset, (float)p.r0, (float)k.e,
@@ -853,6 +959,48 @@ int hw_profile_read(hw_ctx* c, float* ms, int32_t cap, int32_t* n_out)
     *n_out = n;
     c->prof_cap = 0;
     c->prof_used = 0;
+    return HW_OK;
+}
+
+int hw_profile_spans(hw_ctx* c, hw_ctx* ref, float* start_ms, float* end_ms, int32_t cap, int32_t* n_out)
+{
+    if (!c || !ref || !start_ms || !end_ms || !n_out) return fail(HW_E_INVALID, "null argument");
+    if (c->device != ref->device) return fail(HW_E_INVALID, "contexts on different devices have no common event clock");
+    if (ref->prof_used < 1) return fail(HW_E_INVALID, "the reference context has no profiled launch");
+    HIP_TRY(hipSetDevice(c->device));
+    const int n = std::min(c->prof_used, (int)cap);
+    HIP_TRY(hipEventSynchronize(ref->prof_ev[0]));
+    for (int i = 0; i < n; i++) {
+        HIP_TRY(hipEventSynchronize(c->prof_ev[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&start_ms[i], ref->prof_ev[0], c->prof_ev[2 * i]));
+        HIP_TRY(hipEventElapsedTime(&end_ms[i], ref->prof_ev[0], c->prof_ev[2 * i + 1]));
+    }
+    *n_out = n;
+    return HW_OK;
+}
+
+int hw_get_launch_geometry(hw_ctx* c, const char* kernel, int64_t n_units, int32_t* block, int32_t* grid, int32_t* iters,
+                           int64_t* partial_bytes)
+{
+    if (!c || !kernel) return fail(HW_E_INVALID, "null argument");
+    if (n_units < 0) return fail(HW_E_INVALID, "n_units < 0");
+    Geometry g{};
+    int64_t row = 0;
+    if (!strcmp(kernel, "zbc") || !strcmp(kernel, "zbc_ref")) { g = geometry(c, n_units, !strcmp(kernel, "zbc") ? c->ilp : 1); row = 5 * 8; }
+    else if (!strcmp(kernel, "vega")) { g = geometry(c, n_units, c->ilp); row = 8; }
+    else if (!strcmp(kernel, "zcb") || !strcmp(kernel, "zcb_blocked")) {
+        int P = 1;
+        if (!strcmp(kernel, "zcb_blocked")) {
+            const int64_t resident = (int64_t)c->prop.multiProcessorCount * 2048;
+            P = n_units >= 8 * resident ? 4 : n_units >= 4 * resident ? 2 : 1;
+        }
+        g = geometry(c, n_units, P, true);
+        row = (int64_t)c->p.n_mat * 8;
+    } else return fail(HW_E_INVALID, "unknown kernel '%s'", kernel);
+    if (block) *block = g.block;
+    if (grid) *grid = g.grid;
+    if (iters) *iters = g.iters;
+    if (partial_bytes) *partial_bytes = row * g.grid;
     return HW_OK;
 }
 
@@ -1002,6 +1150,12 @@ int hw_analytic_curve(const hw_params* p, float* P, float* f)
 }  // extern "C"
 
 // ---- multi-GPU in one process: shard over several contexts, one RCCL all-reduce over xGMI ----------
+// One PERSISTENT host thread per device (created by hw_comm_create, bound to its device once): a pricing call hands
+// every worker the same job; worker g enqueues its shard's kernels on context g's stream, enqueues the all-reduce on
+// the same stream, and waits for that stream.  The devices therefore start within the wake-up jitter of the workers
+// (they spin for a short while after each job before they sleep on a condition variable) instead of one launch
+// latency after another: the single-threaded version of round 1 walked the devices in a loop, ~5 us of skew per
+// device, which alone capped the strong scaling of a 2^24-pair call at ~6.6x on 8 GPUs.
 struct hw_comm {
     std::vector<hw_ctx*> ctx;
     std::vector<ncclComm_t> comm;
@@ -1012,6 +1166,16 @@ struct hw_comm {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    // workers
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::atomic<uint64_t> generation{0};
+    std::atomic<int> pending{0};
+    bool quit = false;
+    const std::function<int(int)>* job = nullptr;
+    std::vector<int> rc;
+    std::vector<std::string> err;
 };
 
 #define NCCL_TRY(cm, expr)                                                                              \
@@ -1028,39 +1192,84 @@ static void comm_shard(int64_t n, int g, int G, int64_t* off, int64_t* cnt)
     *cnt = base + (g < rem ? 1 : 0);
 }
 
-// enqueue(g, offset, count, d_out, stream) on every device, then ONE grouped all-reduce of `count_out` doubles
+static void comm_worker(hw_comm* cm, int g)
+{
+    (void)hipSetDevice(cm->ctx[g]->device);
+    uint64_t seen = 0;
+    for (;;) {
+        // hybrid wait: spin ~100 us (back-to-back pricing calls never pay a futex wake-up), then sleep
+        bool got = false;
+        const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(100);
+        while (std::chrono::steady_clock::now() < spin_until) {
+            if (cm->generation.load(std::memory_order_acquire) != seen) { got = true; break; }
+            __builtin_ia32_pause();
+        }
+        if (!got) {
+            std::unique_lock<std::mutex> lk(cm->mu);
+            cm->cv_job.wait(lk, [&] { return cm->quit || cm->generation.load(std::memory_order_acquire) != seen; });
+            if (cm->quit) return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(cm->mu);      // (job and quit are written under the mutex)
+            if (cm->quit) return;
+        }
+        seen = cm->generation.load(std::memory_order_acquire);
+        const int r = (*cm->job)(g);
+        cm->rc[g] = r;
+        cm->err[g] = r ? g_err : std::string();         // hw_last_error() is per thread: hand the text to the caller's
+        if (cm->pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+            std::lock_guard<std::mutex> lk(cm->mu);
+            cm->cv_done.notify_one();
+        }
+    }
+}
+
+// run job(g) on every worker, wait for all of them; first failure wins
+static int comm_dispatch(hw_comm* cm, const std::function<int(int)>& job)
+{
+    const int G = (int)cm->ctx.size();
+    {
+        std::lock_guard<std::mutex> lk(cm->mu);
+        cm->job = &job;
+        cm->pending.store(G, std::memory_order_release);
+        cm->generation.fetch_add(1, std::memory_order_acq_rel);
+    }
+    cm->cv_job.notify_all();
+    {
+        std::unique_lock<std::mutex> lk(cm->mu);
+        cm->cv_done.wait(lk, [&] { return cm->pending.load(std::memory_order_acquire) == 0; });
+        cm->job = nullptr;
+    }
+    for (int g = 0; g < G; g++)
+        if (cm->rc[g] != HW_OK) return fail(cm->rc[g], "device %d: %s", cm->ctx[g]->device, cm->err[g].c_str());
+    return HW_OK;
+}
+
+// enqueue(g, offset, count, d_out, stream) on every device (by that device's worker), then ONE all-reduce of
+// `count_out` doubles per device on the same stream; worker 0 also brings the reduced vector to the host
 template <typename F>
 static int comm_run(hw_comm* cm, int64_t n_units, int count_out, double* out, float* wall_ms, F enqueue)
 {
     if (count_out > kOutCap) return fail(HW_E_INVALID, "too many outputs");
     const int G = (int)cm->ctx.size();
     const auto t0 = std::chrono::steady_clock::now();
-    for (int g = 0; g < G; g++) {
+    const std::function<int(int)> job = [&](int g) -> int {
         hw_ctx* c = cm->ctx[g];
-        HIP_TRY(hipSetDevice(c->device));
         int64_t off, cnt;
         comm_shard(n_units, g, G, &off, &cnt);
-        int rc = enqueue(g, off, cnt, c->d_out, c->stream);          // asynchronous: all devices run concurrently
+        int rc = enqueue(g, off, cnt, c->d_out, c->stream);
         if (rc) return rc;
-    }
-    NCCL_TRY(cm, cm->GroupStart());
-    for (int g = 0; g < G; g++) {
-        hw_ctx* c = cm->ctx[g];
-        const ncclResult_t r = cm->AllReduce(c->d_out, c->d_out, (size_t)count_out, ncclDouble, ncclSum, cm->comm[g], c->stream);
-        if (r != ncclSuccess) {
-            (void)cm->GroupEnd();                                    // never leave the group open
-            return fail(HW_E_HIP, "RCCL error [ncclAllReduce, device %d]: %s", c->device, cm->GetErrorString(r));
-        }
-    }
-    NCCL_TRY(cm, cm->GroupEnd());
-    HIP_TRY(hipSetDevice(cm->ctx[0]->device));
-    HIP_TRY(hipMemcpyAsync(out, cm->ctx[0]->d_out, count_out * sizeof(double), hipMemcpyDeviceToHost, cm->ctx[0]->stream));
-    for (int g = 0; g < G; g++) {
-        HIP_TRY(hipSetDevice(cm->ctx[g]->device));
-        HIP_TRY(hipStreamSynchronize(cm->ctx[g]->stream));
-    }
+        // one communicator per thread: no group call needed (each rank's call comes from its own thread, as in the
+        // one-process-per-GPU layout)
+        NCCL_TRY(cm, cm->AllReduce(c->d_out, c->d_out, (size_t)count_out, ncclDouble, ncclSum, cm->comm[g], c->stream));
+        if (g == 0) HIP_TRY(hipMemcpyAsync(out, c->d_out, count_out * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        free_retired(c);
+        return HW_OK;
+    };
+    const int rc = comm_dispatch(cm, job);
     if (wall_ms) *wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return HW_OK;
+    return rc;
 }
 
 extern "C" {
@@ -1098,6 +1307,9 @@ int hw_comm_create(int32_t n, hw_ctx* const* ctxs, hw_comm** out)
         delete cm;
         return fail(HW_E_HIP, "ncclCommInitAll: %s", msg);
     }
+    cm->rc.assign(n, 0);
+    cm->err.assign(n, std::string());
+    for (int g = 0; g < n; g++) cm->workers.emplace_back(comm_worker, cm, g);
     *out = cm;
     return HW_OK;
 }
@@ -1105,6 +1317,13 @@ int hw_comm_create(int32_t n, hw_ctx* const* ctxs, hw_comm** out)
 void hw_comm_destroy(hw_comm* cm)
 {
     if (!cm) return;
+    {
+        std::lock_guard<std::mutex> lk(cm->mu);
+        cm->quit = true;
+        cm->generation.fetch_add(1, std::memory_order_acq_rel);
+    }
+    cm->cv_job.notify_all();
+    for (std::thread& t : cm->workers) t.join();
     for (size_t i = 0; i < cm->comm.size(); i++) {
         (void)hipSetDevice(cm->ctx[i]->device);
         (void)cm->CommDestroy(cm->comm[i]);

@@ -334,6 +334,24 @@ __device__ __forceinline__ double hw_fma(double a, double b, double c) { return 
 __device__ __forceinline__ float  hw_max0(float a)  { return fmaxf(a, 0.0f); }
 __device__ __forceinline__ double hw_max0(double a) { return fmax(a, 0.0); }
 
+// Optional per-workgroup timeline (diagnostic; tools/timeline_probe.hip): s_memrealtime (100 MHz) at the entry and
+// exit of every workgroup into stamps[2 b], stamps[2 b + 1].  The engine always passes nullptr.
+struct WorkgroupStamp {
+    unsigned long long t0;
+    __device__ __forceinline__ void begin(const unsigned long long* stamps)
+    {
+        t0 = 0;
+        if (stamps != nullptr && threadIdx.x == 0) t0 = __builtin_amdgcn_s_memrealtime();
+    }
+    __device__ __forceinline__ void end(unsigned long long* stamps) const
+    {
+        if (stamps != nullptr && threadIdx.x == 0) {
+            stamps[2 * (size_t)blockIdx.x] = t0;
+            stamps[2 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+};
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -386,6 +404,193 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v)
     v += dpp_mov<0x142, 0xa>(v);
     v += dpp_mov<0x143, 0xc>(v);
     return v;
+}
+
+// Sum over each DPP row of 16 lanes; EVERY lane of the row ends with its row's sum (the first four steps of
+// wave_sum_to_lane63: 4 v_add_*_dpp for a float, 8 v_mov_b32_dpp + 4 v_add_f64 for a double).
+__device__ __forceinline__ float row_sum16(float v)
+{
+    v += dpp_mov<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xf>(v);   // row_half_mirror
+    v += dpp_mov<0x140, 0xf>(v);   // row_mirror
+    return v;
+}
+__device__ __forceinline__ double row_sum16(double v)
+{
+    v += dpp_mov<0xB1, 0xf>(v);
+    v += dpp_mov<0x4E, 0xf>(v);
+    v += dpp_mov<0x141, 0xf>(v);
+    v += dpp_mov<0x140, 0xf>(v);
+    return v;
+}
+
+// Per-wave accumulation of one value per maturity (the curve kernels: 100 reductions over the lanes inside the time
+// loop, market_data.cuh:57-64).  The reference reduces the warp and lets lane 0 do a shared-memory atomic per
+// maturity; the first version here reduced the wave to lane 63 (6 DPP steps) and had that lane read-modify-write a
+// double in LDS (+ cvt + f64 add + the LDS round trip): ~50 of the ~85 issue cycles a maturity cost a wave.
+// Now: 4 DPP steps give every lane its row-of-16 sum, and ONE register per wave collects 16 maturities: lane
+// 16 r + i of `A` holds row r's running sum for maturity 16 g + i of the current group g (a single v_add under a
+// lane mask).  Every 16th maturity the register is added, in double, to the wave's own LDS tile [groups][64] and
+// cleared -- one LDS access per 16 maturities, no atomics, no cross-wave traffic, fixed order: bit-reproducible.
+template <typename REAL>
+struct MaturitySlots {
+    REAL A;
+    double* tile;      // this wave's [n_groups][64] doubles in LDS
+    int lane, lane15;
+    __device__ __forceinline__ void init(double* wave_tile)
+    {
+        A = 0;
+        tile = wave_tile;
+        lane = threadIdx.x & (kWave - 1);
+        lane15 = lane & 15;
+    }
+    __device__ __forceinline__ void flush(int group)
+    {
+        tile[group * kWave + lane] += (double)A;
+        A = 0;
+    }
+    // m (wave-uniform) in 1 .. n_mat-1; q: this lane's value for maturity m
+    __device__ __forceinline__ void add(int ev, int m, int n_mat, const REAL& q)
+    {
+        if (ev == 0 || m >= n_mat) return;
+        const REAL rs = row_sum16(q);
+        if (lane15 == (m & 15)) A += rs;
+        if ((m & 15) == 15) flush(m >> 4);
+    }
+    // after the last maturity of a path: the group in progress, unless add() has just flushed it
+    __device__ __forceinline__ void finish(int n_mat)
+    {
+        if (((n_mat - 1) & 15) != 15) flush((n_mat - 1) >> 4);
+    }
+};
+__host__ __device__ inline int maturity_groups(int n_mat) { return (n_mat + 15) >> 4; }
+
+// The same job with a TRANSPOSED reduction: instead of reducing every maturity's 16 lane values to one number
+// (4 DPP adds) and then picking one lane to keep it (compare + add + select), sixteen consecutive maturities are
+// reduced TOGETHER, so that lane l of each row ends with the row sum of ONE of them.  Merging two vectors a (older
+// maturity) and b (newer) at level L keeps a's half on the lanes whose class bit b_L is 0 and b's half on the others:
+//     keep = b_L ? b : a;   send = b_L ? a : b;   merged = keep + dpp_L(send)          (2 v_cndmask + 1 v_add_dpp)
+// and the merged vector represents both maturities in half as many lanes each.  The maturities arrive one at a time, so
+// the pending vectors sit in a binary counter h0..h3: maturity k (= m mod 16) merges upwards through as many levels as
+// k has trailing one bits -- 15 merges per 16 maturities, 2.9 VALU instructions per maturity instead of 7 -- and the
+// sixteenth leaves one register that goes, in double, to the wave's LDS tile: one LDS access per 16 maturities.
+// DPP partners: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror (l -> l ^ 7), row_mirror (l -> l ^ 15); the class
+// bits that make these four involutions a valid butterfly are b0 = l0^l2, b1 = l1^l2, b2 = l2^l3, b3 = l3 (l = lane & 15):
+// each partner map flips exactly its own level's bit and none below it.  Lane l ends with maturity
+// k = b0 + 2 b1 + 4 b2 + 8 b3 of the group; tree_lane_of() is the inverse.  Wave-uniform scalar branches only.
+struct MaturityTree {
+    float h0, h1, h2, h3;
+    unsigned long long m0, m1, m2, m3;     // lane masks of the class bits (SGPR pairs)
+    double* tile;      // this wave's [n_groups][64] doubles in LDS
+    int lane;
+    __device__ __forceinline__ void init(double* wave_tile)
+    {
+        tile = wave_tile;
+        lane = threadIdx.x & (kWave - 1);
+        const int l0 = lane & 1, l1 = (lane >> 1) & 1, l2 = (lane >> 2) & 1, l3 = (lane >> 3) & 1;
+        m0 = __builtin_amdgcn_ballot_w64((l0 ^ l2) != 0);
+        m1 = __builtin_amdgcn_ballot_w64((l1 ^ l2) != 0);
+        m2 = __builtin_amdgcn_ballot_w64((l2 ^ l3) != 0);
+        m3 = __builtin_amdgcn_ballot_w64(l3 != 0);
+        h0 = h1 = h2 = h3 = 0.0f;   // maturity 0 is never simulated: level 0 starts with a zero vector pending
+    }
+    // m (wave-uniform) in 1 .. ; q: this lane's value for maturity m.
+    // One asm statement: written in C++ the four pending vectors became phi nodes of the time loop and the compiler
+    // paid for them with eight v_mov_b32 in EVERY Philox block (7 % of the loop); as tied asm operands they are updated
+    // in place.  v_cndmask_b32 dst, a, b, mask = mask ? b : a;  v_add_f32_dpp dst, x, y = dpp(x) + y; a VALU result
+    // needs two wait states before a DPP instruction may read it (s_nop 1).
+    // `go` (wave-uniform): false = nothing to add in this call.  The test sits INSIDE the asm statement so that the
+    // statement runs on every trip of the time loop: the pending vectors never pass through a phi node.
+    // (The gate is passed as the integers it is made of, ev != 0 and m < n_mat: a bool would reach the asm through a
+    // v_cndmask, i.e. in a vector register.)
+    __device__ __forceinline__ void add(int ev, int m, int n_mat, float& v /* in: q; out: scratch */)
+    {
+        const int k = m & 15;
+        float t;
+        asm volatile(
+            "s_cmp_eq_u32 %[ev], 0\n\t"
+            "s_cbranch_scc1 9f\n\t"
+            "s_cmp_ge_i32 %[m], %[nm]\n\t"
+            "s_cbranch_scc1 9f\n\t"
+            "s_bitcmp1_b32 %[k], 0\n\t"
+            "s_cbranch_scc1 1f\n\t"
+            "v_mov_b32 %[h0], %[v]\n\t"
+            "s_branch 9f\n"
+            "1:\n\t"
+            "v_cndmask_b32_e64 %[t], %[v], %[h0], %[m0]\n\t"
+            "v_cndmask_b32_e64 %[v], %[h0], %[v], %[m0]\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %[v], %[t], %[v] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "s_bitcmp1_b32 %[k], 1\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "v_mov_b32 %[h1], %[v]\n\t"
+            "s_branch 9f\n"
+            "2:\n\t"
+            "v_cndmask_b32_e64 %[t], %[v], %[h1], %[m1]\n\t"
+            "v_cndmask_b32_e64 %[v], %[h1], %[v], %[m1]\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %[v], %[t], %[v] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "s_bitcmp1_b32 %[k], 2\n\t"
+            "s_cbranch_scc1 3f\n\t"
+            "v_mov_b32 %[h2], %[v]\n\t"
+            "s_branch 9f\n"
+            "3:\n\t"
+            "v_cndmask_b32_e64 %[t], %[v], %[h2], %[m2]\n\t"
+            "v_cndmask_b32_e64 %[v], %[h2], %[v], %[m2]\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %[v], %[t], %[v] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "s_bitcmp1_b32 %[k], 3\n\t"
+            "s_cbranch_scc1 4f\n\t"
+            "v_mov_b32 %[h3], %[v]\n\t"
+            "s_branch 9f\n"
+            "4:\n\t"
+            "v_cndmask_b32_e64 %[t], %[v], %[h3], %[m3]\n\t"
+            "v_cndmask_b32_e64 %[v], %[h3], %[v], %[m3]\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %[v], %[t], %[v] row_mirror row_mask:0xf bank_mask:0xf\n"
+            "9:\n\t"
+            : [v] "+v"(v), [t] "=&v"(t), [h0] "+v"(h0), [h1] "+v"(h1), [h2] "+v"(h2), [h3] "+v"(h3)
+            : [k] "s"(k), [ev] "s"(ev), [m] "s"(m), [nm] "s"(n_mat), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3)
+            : "scc");
+        if (ev != 0 && m < n_mat && k == 15) tile[(m >> 4) * kWave + lane] += (double)v;   // sixteen merged: lane l holds maturity class(l)
+    }
+    // after the last maturity of a path: complete the group in progress with zero vectors, re-arm for the next path
+    __device__ __forceinline__ void finish(int n_mat)
+    {
+        for (int m = n_mat; (m & 15) != 0; m++) {
+            float zero = 0.0f;
+            add(1, m, m + 1, zero);
+        }
+        h0 = 0.0f;
+    }
+};
+// lane (within a row of 16) that holds maturity k of a group once the tree has flushed it
+__host__ __device__ inline int tree_lane_of(int k)
+{
+    const int l3 = (k >> 3) & 1, l2 = ((k >> 2) & 1) ^ l3, l1 = ((k >> 1) & 1) ^ l2, l0 = (k & 1) ^ l2;
+    return l0 | (l1 << 1) | (l2 << 2) | (l3 << 3);
+}
+
+#ifndef HWK_MATURITY_TREE
+#define HWK_MATURITY_TREE 1       // 0: MaturitySlots (A/B)
+#endif
+// the blocked float kernel uses the tree, the generic (double / odd stride) kernel the slots
+
+// workgroup epilogue of the curve kernels: partials[block][k] = sum over waves and rows of the tiles' slot of maturity k
+template <bool TREE>
+__device__ __forceinline__ void maturity_tiles_to_partials(const double* s_tiles, int nwaves, int n_mat,
+                                                           double* __restrict__ partials)
+{
+    const int groups = maturity_groups(n_mat);
+    for (int k = threadIdx.x; k < n_mat; k += blockDim.x) {
+        double tsum = 0.0;
+        for (int w = 0; w < nwaves; w++) {
+            const double* t = s_tiles + ((size_t)w * groups + (k >> 4)) * kWave + (TREE ? tree_lane_of(k & 15) : (k & 15));
+            tsum += (t[0] + t[16]) + (t[32] + t[48]);
+        }
+        partials[(size_t)blockIdx.x * n_mat + k] = tsum;
+    }
 }
 
 // Finish of a sum over the whole grid.  Every workgroup reduces its threads' N values (lane tree,
@@ -532,6 +737,9 @@ __global__ void finalize_columns_kernel(const double* __restrict__ partials, int
 #ifndef HWK_ANGLE_BITS
 #define HWK_ANGLE_BITS 0
 #endif
+#ifndef HWK_F64_BLOCK_FORM
+#define HWK_F64_BLOCK_FORM 1     // 0: the double stepper runs one fma + one add per step on converted normals (A/B)
+#endif
 __device__ __forceinline__ void box_muller_parts(uint32_t x, uint32_t y, float& s, float& sn, float& cs)
 {
     constexpr float kInv = 2.3283064e-10f;
@@ -650,6 +858,54 @@ __device__ __forceinline__ void ou_walk(const PhiloxKey& key, const PhiloxPath (
 #pragma unroll
         for (int q = 0; q < ILP; q++) S[q] = (W[q] - e * y[q]) * inv;
       }
+    } else if (sizeof(REAL) == sizeof(double) && HWK_F64_BLOCK_FORM) {
+        // double (y, W) form.  The same algebra as the float form above, with the recursion state in double: the
+        // two block inputs  t0 = s0 (e sin0 + cos0),  t1 = s1 (e sin1 + cos1)  and the block's sum of normals
+        // u = s0 (sin0 + cos0) + s1 (sin1 + cos1)  are formed in float from the raw Box-Muller parts (the normals are
+        // float products anyway), converted once, and  y4 = e^2 (e^2 y0 + t0) + t1,  W += u  run in double:
+        // 3 v_cvt_f64_f32 + 2 v_fma_f64 + 1 v_add_f64 per block instead of 4 + 4 + 4 (and no separate float
+        // products for the normals).  The division by 1 - e at the end is harmless in double: no guard needed.
+        const double e2 = (double)e * (double)e;
+        const float ef = (float)e;
+        double W[ILP];
+#pragma unroll
+        for (int q = 0; q < ILP; q++) W[q] = 0.0;
+        auto blocks = [&](auto tag) {
+            constexpr bool UHI = decltype(tag)::value;
+            for (int j = 0; j < nblk; j++) {
+#pragma unroll
+                for (int q = 0; q < ILP; q++) {
+                    uint32_t w0, w1, w2, w3;
+                    float s0, sn0, cs0, s1, sn1, cs1;
+                    philox_block_prio<UHI, true, 0>(key, pp[q], a2s[q], (uint32_t)j, w0, w1, w2, w3);
+                    box_muller_parts(w0, w1, s0, sn0, cs0);
+                    box_muller_parts(w2, w3, s1, sn1, cs1);
+                    const float t0 = s0 * __builtin_fmaf(ef, sn0, cs0), t1 = s1 * __builtin_fmaf(ef, sn1, cs1);
+                    const float u = __builtin_fmaf(s1, sn1 + cs1, s0 * (sn0 + cs0));
+                    y[q] = (REAL)__builtin_fma(e2, __builtin_fma(e2, (double)y[q], (double)t0), (double)t1);
+                    W[q] += (double)u;
+                }
+            }
+        };
+        if (uhi) blocks(std::true_type{});
+        else blocks(std::false_type{});
+        if (rem) {                                    // wave-uniform tail: 1..3 single steps
+#pragma unroll
+            for (int q = 0; q < ILP; q++) {
+                float g[4];
+                normal4_prio(key, pp[q], (uint32_t)nblk, g);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    if (c < rem) {
+                        y[q] = hw_fma(y[q], e, (REAL)g[c]);
+                        W[q] += (double)g[c];
+                    }
+                }
+            }
+        }
+        const double inv = 1.0 / (1.0 - (double)e);
+#pragma unroll
+        for (int q = 0; q < ILP; q++) S[q] = (REAL)((W[q] - (double)e * (double)y[q]) * inv);
     } else {
         auto blocks = [&](auto tag) {
             constexpr bool UHI = decltype(tag)::value;
@@ -706,6 +962,7 @@ struct ZbcArgs {
     REAL e;
     ZbcScen<REAL> sc[NSCEN];
     unsigned long long* clk;   // optional: workgroup 0 stores {s_memtime, s_memrealtime} at entry and exit
+    unsigned long long* stamps; // optional: every workgroup's entry/exit s_memrealtime (WorkgroupStamp)
     // several independent runs in one launch (the 20-run validation, 2_option:210-468): workgroup b belongs
     // to run b / blocks_per_run and uses seed + run * seed_stride.  One run: blocks_per_run = gridDim.x.
     uint32_t blocks_per_run;
@@ -718,6 +975,8 @@ zbc_superposed_kernel(const ZbcArgs<REAL, NSCEN> a, double* __restrict__ partial
                       unsigned* __restrict__ ticket, double* __restrict__ out)
 {
     __shared__ double smem[kMaxWaves * 5 * NSCEN];
+    WorkgroupStamp wg_stamp;
+    wg_stamp.begin(a.stamps);
     // clock probe (diagnostic only; the stamps go to a buffer nothing else reads)
     const bool stamp = a.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     if (stamp) {
@@ -775,6 +1034,7 @@ zbc_superposed_kernel(const ZbcArgs<REAL, NSCEN> a, double* __restrict__ partial
         a.clk[2] = __builtin_amdgcn_s_memtime();
         a.clk[3] = __builtin_amdgcn_s_memrealtime();
     }
+    wg_stamp.end(a.stamps);      // (before the cross-wave finish: the stamp is the end of this workgroup's path work)
     grid_sum_finish<5 * NSCEN>(acc, smem, partials, ticket, out);
 }
 
@@ -863,11 +1123,8 @@ zbc_reference_kernel(const ZbcRefArgs a, const float* __restrict__ drift, double
 // ------------------------------------------------------------------------------------------
 // Zero-coupon curve: every `stride` steps add exp(-I1)+exp(-I2) = D0_m (2^{z'} + 2^{-z'}) to
 // maturity m.  The lane-invariant factor D0_m is applied in double by finalize_columns_kernel.
-// Per-wave running sums live in LDS as doubles: row [wave][n_mat], touched by lane 0 only.
+// Per-wave running sums: MaturitySlots (one register per 16 maturities, flushed to the wave's LDS tile in double).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float  curve_wave_sum(float q)  { return wave_sum_to_lane63(q); }
-__device__ __forceinline__ double curve_wave_sum(double q) { return wave_sum_to_lane63(q); }
-
 template <typename REAL>
 struct ZcbArgs {
     int64_t n_pairs;
@@ -881,12 +1138,14 @@ template <typename REAL>
 __global__ void __launch_bounds__(1024)
 zcb_curve_kernel(const ZcbArgs<REAL> a, double* __restrict__ partials)
 {
-    extern __shared__ double s_rows[];                 // [nwaves][n_mat]
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    extern __shared__ double s_tiles[];                // [nwaves][groups][64], see MaturityTree
+    const int wave = threadIdx.x >> 6;
     const int nwaves = (blockDim.x + kWave - 1) >> 6;
-    for (int i = threadIdx.x; i < nwaves * a.n_mat; i += blockDim.x) s_rows[i] = 0.0;
+    const int groups = maturity_groups(a.n_mat);
+    for (int i = threadIdx.x; i < nwaves * groups * kWave; i += blockDim.x) s_tiles[i] = 0.0;
     __syncthreads();
-    double* row = s_rows + wave * a.n_mat;
+    MaturitySlots<REAL> slots;
+    slots.init(s_tiles + (size_t)wave * groups * kWave);
 
     const PhiloxKey key = philox_key(a.seed);
     PhiloxKey vkey = key;                           // round keys 3..10 in vector registers for the loop
@@ -921,8 +1180,7 @@ zcb_curve_kernel(const ZcbArgs<REAL> a, double* __restrict__ partials)
                                 const REAL z = a.cz * (S - (REAL)0.5 * y);
                                 REAL q = hw_exp2(z) + hw_exp2(-z);         // market_data.cuh:60
                                 if (!valid) q = 0;
-                                const REAL qs = curve_wave_sum(q);         // market_data.cuh:61
-                                if (lane == kWave - 1) row[m] += (double)qs;   // market_data.cuh:62-64
+                                slots.add(1, m, a.n_mat, q);               // market_data.cuh:61-64
                             }
                         }
                     }
@@ -932,13 +1190,10 @@ zcb_curve_kernel(const ZcbArgs<REAL> a, double* __restrict__ partials)
         if (uhi) walk(std::true_type{});
         else walk(std::false_type{});
         HWK_SETPRIO(0);
+        slots.finish(a.n_mat);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < a.n_mat; k += blockDim.x) {
-        double tsum = 0.0;
-        for (int w = 0; w < nwaves; w++) tsum += s_rows[w * a.n_mat + k];
-        partials[(size_t)blockIdx.x * a.n_mat + k] = tsum;
-    }
+    maturity_tiles_to_partials<false>(s_tiles, nwaves, a.n_mat, partials);
 }
 
 // Blocked float form of the curve kernel (n_steps % 4 == 0, stride even and >= 4; everything else runs the
@@ -954,18 +1209,27 @@ struct ZcbBlockedArgs {
     uint64_t seed, path_offset;
     int32_t n_steps, n_mat, stride, iters;
     float e, e2, c1, c2;
+    unsigned long long* stamps;     // nullptr, or the timeline buffer (WorkgroupStamp)
 };
 
 template <int P>
 __global__ void __launch_bounds__(1024)
 zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
 {
-    extern __shared__ double s_rows[];                 // [nwaves][n_mat]
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    extern __shared__ double s_tiles[];                // [nwaves][groups][64], see MaturityTree
+    WorkgroupStamp stamp;
+    stamp.begin(a.stamps);
+    const int wave = threadIdx.x >> 6;
     const int nwaves = (blockDim.x + kWave - 1) >> 6;
-    for (int i = threadIdx.x; i < nwaves * a.n_mat; i += blockDim.x) s_rows[i] = 0.0;
+    const int groups = maturity_groups(a.n_mat);
+    for (int i = threadIdx.x; i < nwaves * groups * kWave; i += blockDim.x) s_tiles[i] = 0.0;
     __syncthreads();
-    double* row = s_rows + wave * a.n_mat;
+#if HWK_MATURITY_TREE
+    MaturityTree slots;
+#else
+    MaturitySlots<float> slots;
+#endif
+    slots.init(s_tiles + (size_t)wave * groups * kWave);
 
     const PhiloxKey key = philox_key(a.seed);
     PhiloxKey vkey = key;
@@ -996,7 +1260,12 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
             int to_event = half_stride, m = 0;         // half blocks until the next maturity
             for (int j = 0; j < nblk; j++) {
                 const int ev = to_event <= 2 ? to_event : 0;               // 1: after the first half, 2: after the second
-                float accq = 0.0f;
+                float accq;                                                // assigned by q == 0 of an event block
+                auto contribute = [&](int q) {
+                    const float z = __builtin_fmaf(a.c1, W[q], -a.c2 * y[q]);
+                    const float c = hw_exp2(z) + hw_exp2(-z);              // market_data.cuh:60
+                    accq = q == 0 ? live[q] * c : __builtin_fmaf(live[q], c, accq);
+                };
 #pragma unroll
                 for (int q = 0; q < P; q++) {
                     uint32_t w0, w1, w2, w3;
@@ -1006,39 +1275,33 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
                     box_muller_parts(w2, w3, s1, sn1, cs1);
                     y[q] = __builtin_fmaf(a.e2, y[q], s0 * __builtin_fmaf(a.e, sn0, cs0));
                     W[q] = __builtin_fmaf(s0, sn0 + cs0, W[q]);
-                    if (ev == 1) {                                         // wave-uniform
-                        const float z = __builtin_fmaf(a.c1, W[q], -a.c2 * y[q]);
-                        accq = __builtin_fmaf(live[q], hw_exp2(z) + hw_exp2(-z), accq);     // market_data.cuh:60
+                    // ev is wave-uniform: these are scalar branches.  The empty volatile asm keeps the compiler from
+                    // if-converting them (it did: both pairs of v_exp_f32 ran in every event block and a v_cndmask
+                    // picked one -- two transcendentals = 16 issue cycles wasted per maturity).
+                    if (ev == 1) {
+                        asm volatile("" ::: "memory");
+                        contribute(q);
                     }
                     y[q] = __builtin_fmaf(a.e2, y[q], s1 * __builtin_fmaf(a.e, sn1, cs1));
                     W[q] = __builtin_fmaf(s1, sn1 + cs1, W[q]);
                     if (ev == 2) {
-                        const float z = __builtin_fmaf(a.c1, W[q], -a.c2 * y[q]);
-                        accq = __builtin_fmaf(live[q], hw_exp2(z) + hw_exp2(-z), accq);
+                        asm volatile("" ::: "memory");
+                        contribute(q);
                     }
                 }
-                if (ev) {
-                    m++;
-                    if (m < a.n_mat) {                                     // market_data.cuh:59
-                        const float qs = wave_sum_to_lane63(accq);         // market_data.cuh:61
-                        if (lane == kWave - 1) row[m] += (double)qs;       // market_data.cuh:62-64
-                    }
-                    to_event = half_stride - (2 - ev);
-                } else {
-                    to_event -= 2;
-                }
+                m += ev != 0;
+                slots.add(ev, m, a.n_mat, accq);                           // market_data.cuh:59-64 (no-op when ev == 0)
+                to_event = ev ? half_stride - (2 - ev) : to_event - 2;
             }
         };
         if (uhi) blocks(std::true_type{});
         else blocks(std::false_type{});
         HWK_SETPRIO(0);
+        slots.finish(a.n_mat);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < a.n_mat; k += blockDim.x) {
-        double tsum = 0.0;
-        for (int w = 0; w < nwaves; w++) tsum += s_rows[w * a.n_mat + k];
-        partials[(size_t)blockIdx.x * a.n_mat + k] = tsum;
-    }
+    maturity_tiles_to_partials<HWK_MATURITY_TREE != 0>(s_tiles, nwaves, a.n_mat, partials);
+    stamp.end(a.stamps);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -130,6 +130,21 @@ class HullWhiteEngine:
         L.check(self.lib.hw_profile_read(self._ctx, _fp(ms), cap, C.byref(n)))
         return ms[:n.value].copy()
 
+    def profile_spans(self, ref=None, cap=100000):
+        """(start_ms, end_ms) of every profiled launch, relative to the first profiled launch of `ref` (default: self).
+        Call before profile_read()."""
+        st = np.zeros(cap, np.float32)
+        en = np.zeros(cap, np.float32)
+        n = C.c_int32(0)
+        L.check(self.lib.hw_profile_spans(self._ctx, (ref or self)._ctx, _fp(st), _fp(en), cap, C.byref(n)))
+        return st[:n.value].copy(), en[:n.value].copy()
+
+    def launch_geometry(self, kernel, n_units):
+        b, g, it, pb = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int64(0)
+        L.check(self.lib.hw_get_launch_geometry(self._ctx, kernel.encode(), int(n_units), C.byref(b), C.byref(g),
+                                                C.byref(it), C.byref(pb)))
+        return {"block": b.value, "grid": g.value, "iters": it.value, "partial_bytes": pb.value}
+
     def profile_clock_mhz(self):
         """Shader clock held during the last profiled superposed-ZBC launch (in-kernel probe)."""
         mhz = C.c_double(0.0)

@@ -33,3 +33,38 @@ def sharded_sums(local_fn, n_total, device="cpu", group=None):
     t = torch.as_tensor(local_fn(cnt, off), dtype=torch.float64, device=device).clone()
     allreduce_sums(t, group=group)
     return t
+
+
+class StepReducer:
+    """Which steps' sums travel together.  A pricing run makes K steps; step i leaves its sums in row i of a
+    [K, n] tensor.  `every` = 1 sends ONE all-reduce per pricing call (the default), `every` = B
+    one message per B consecutive steps, `every` = 0 a single message after the last step.  The caller supplies
+    `reduce_rows(i0, i1, producers)`: all-reduce rows i0..i1 (contiguous) once the launches of `producers` (opaque
+    handles, e.g. stream indices) have finished, returning a work handle or None.  bench.py passes an RCCL
+    all-reduce on a stream of its own; tests/test_distributed_gloo.py a gloo one."""
+
+    def __init__(self, every, n_steps, reduce_rows):
+        self.bucket = max(1, int(every)) if every > 0 else max(1, int(n_steps))
+        self.reduce_rows = reduce_rows
+        self.first = None
+        self.producers = []
+
+    def after_step(self, i, producer=None, last=False):
+        """Call after step i has been enqueued; returns the work handle of the message it completed, if any."""
+        if self.first is None:
+            self.first = i
+        if producer is not None and producer not in self.producers:
+            self.producers.append(producer)
+        if last or i - self.first + 1 >= self.bucket:
+            i0, prods = self.first, self.producers
+            self.first, self.producers = None, []
+            return self.reduce_rows(i0, i, prods)
+        return None
+
+
+def pricing_workload(n_gpus, scaling="strong", pairs_log2=20, total_log2=24):
+    """Pairs per pricing call over all GPUs: N = 1 and weak scaling price 2^pairs_log2 pairs per GPU (BASELINE
+    configs[1]); N > 1 strong scaling shards ONE 2^total_log2-pair call (configs[3]: 2^24)."""
+    if n_gpus == 1 or scaling == "weak":
+        return (1 << pairs_log2) * n_gpus
+    return 1 << total_log2

@@ -34,38 +34,77 @@ def _bench(*args, env=None):
 
 @pytest.mark.parametrize("args,env", [
     (["--gpus", "1", "--steps", "4", "--warmup", "1"], None),
-    (["--steps", "1", "--warmup", "0"], None),
-    (["--steps", "3", "--streams", "1"], None),
-    (["--steps", "3", "--streams", "3", "--paths-log2", "18", "--grid-steps", "4000"], None),
-    (["--steps", "3", "--precision", "f64"], None),
-    (["--steps", "3", "--stepper", "reference", "--profile", "readme"], None),
-    (["--steps", "5", "--warmup", "0", "--allreduce-every", "2"], {"HWMC_BENCH_FORCE_RCCL": "1"}),
-    (["--steps", "4"], {"HWMC_BENCH_FORCE_RCCL": "1"}),
+    (["--steps", "1", "--warmup", "0", "--regions", "1"], None),
+    (["--steps", "3", "--streams", "1", "--no-extras"], None),
+    (["--steps", "3", "--streams", "3", "--paths-log2", "18", "--grid-steps", "4000", "--no-extras"], None),
+    (["--steps", "3", "--precision", "f64", "--no-extras"], None),
+    (["--steps", "3", "--stepper", "reference", "--profile", "readme", "--no-extras"], None),
+    (["--steps", "5", "--warmup", "0", "--allreduce-every", "2", "--no-extras"], {"HWMC_BENCH_FORCE_RCCL": "1"}),
+    (["--steps", "4", "--no-extras"], {"HWMC_BENCH_FORCE_RCCL": "1"}),
+    (["--steps", "4", "--allreduce-every", "0", "--scaling", "weak", "--no-extras"], {"HWMC_BENCH_FORCE_RCCL": "1"}),
 ])
 def test_bench_flag_combinations(args, env):
-    d = _bench(*args, env=env)
+    d = _bench("--regions", "3", *args, env=env) if "--regions" not in args else _bench(*args, env=env)
     assert CONTRACT_KEYS <= set(d), sorted(CONTRACT_KEYS - set(d))
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["n_gpus"] == 1 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["data"] == "synthetic" and d["unit"] == "M paths/s"
-    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert d["scaling"] in ("strong", "weak") and d["data"] == "synthetic" and d["unit"] == "M paths/s"
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_avg",
+                                  "kernel_ms_per_step_in_timed_region", "launch_geometry"}
     assert 0.0 < d["price_mean"] < 0.1 and d["config"]["workload"].startswith("Q2b option_pricing")
     assert d["steps"] == int(args[args.index("--steps") + 1])
+    sp = d["value_spread"]
+    assert sp["min"] <= sp["median"] <= sp["max"] and sp["median"] == d["value"] and len(sp["region_ms"]) == sp["timed_regions"]
+    # the kernels cannot occupy the chip for longer per step than a step lasts (2 % for timer granularity)
+    assert d["roofline"]["kernel_ms_per_step_in_timed_region"] <= 1.02 * d["ms_per_step"]
+    g = d["roofline"]["launch_geometry"]
+    assert g["grid"] * g["block"] * g["iters"] >= d["config"]["pairs_per_gpu"]
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == g["partial_bytes"] + 40
+    if env:
+        assert d["multi_gpu"]["single_call_ms"] > 0 and len(d["multi_gpu"]["per_rank_kernel_ms"]) == 1
 
 
-def test_bench_two_rank_control_flow_rehearsal():
+def test_bench_default_line_carries_the_side_measurements():
+    """No flags beyond a short K: the N = 1 line must hold the other stepper, the 20-run single launch, the Q1 curve kernel
+    at configs[0]'s size and the 2^24-pair strong-scaling reference, all as throughputs in the metric's unit."""
+    d = _bench("--steps", "6", "--regions", "3")
+    for key in ("other_stepper", "runs20_single_launch", "q1_curve_gpu", "strong_scaling_reference", "serial"):
+        assert d[key]["value"] > 0, key
+    assert d["strong_scaling_reference"]["pairs_per_step"] == 1 << 24 and d["config"]["pairs_per_step"] == 1 << 20
+    assert d["scaling"] == "strong" and d["config"]["effective_paths"] == 2 << 20
+    assert d["runs20_single_launch"]["value"] > 0.9 * d["serial"]["value"]
+    assert d["q1_curve_gpu"]["value"] > 391.0                  # the reference's V100 figure for this kernel (README.md:9-12)
+
+
+@pytest.mark.parametrize("every", ["1", "0"])
+def test_bench_two_rank_strong_scaling_rehearsal(every):
     """N = 2 launched exactly as the driver does (torch.distributed.run, one process per rank), in rehearsal mode: both
-    ranks on the one visible GPU, all-reduce over gloo.  Not a measurement -- it pins the multi-rank control flow
-    (sharding by global id, bucketed all-reduce, MAX of the elapsed time over ranks, rank 0 prints ONE line)."""
+    ranks on the one visible GPU, all-reduce over gloo.  Not a measurement -- it pins the multi-rank control flow of
+    the DEFAULT mode: strong scaling of one 2^k-pair pricing call (BASELINE configs[3] at k = 24; k = 18 here), sharded
+    by global pair id, ONE all-reduce per pricing call, MAX of the elapsed time over ranks, rank 0 prints ONE line --
+    and that the reduced sums are the sums one process computes for the whole call, to 1e-13."""
+    import numpy as np
+    import hwmc
     e = dict(os.environ, HWMC_BENCH_REHEARSAL="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--spinup-ms", "50"],
+                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--spinup-ms", "50", "--regions", "2",
+                        "--total-log2", "18", "--allreduce-every", every],
                        capture_output=True, text=True, timeout=400, env=e, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert CONTRACT_KEYS <= set(d) and d["n_gpus"] == 2 and "rehearsal" in d
-    assert d["config"]["effective_paths"] == 2 * 2 * d["config"]["pairs_per_gpu"]
-    # the two shards together price the option: mean of 3 runs of 2^22 samples each
+    assert d["scaling"] == "strong"
+    assert d["config"]["pairs_per_step"] == 1 << 18 and d["config"]["pairs_per_gpu"] == 1 << 17
+    assert d["config"]["effective_paths"] == 2 * (1 << 18)
+    assert d["config"]["allreduce_every"] == int(every)
+    assert "one collective per pricing call" in d["config"]["parallelism"] if every == "1" else "3 steps per message" in d["config"]["parallelism"]
+    p = hwmc.default_params("head")
+    P, f = hwmc.analytic_curve(p)
+    with hwmc.HullWhiteEngine(p, device=0) as eng:
+        eng.load_market_data(P, f)
+        whole = eng.simulate_ZBC_control_variate(1 << 18, 1234)        # the timed steps' first seed (2_option:229)
+    np.testing.assert_allclose(d["sums_step0"], whole, rtol=1e-13)
     assert abs(d["price_mean"] - 0.0252555) < 5e-4
+    assert len(d["multi_gpu"]["per_rank_kernel_ms"]) == 2 and d["multi_gpu"]["single_call_ms"] > 0

@@ -8,49 +8,71 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 #include "hw_kernels.hpp"
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-__global__ void __launch_bounds__(1024) probe_kernel(int n_steps, float e, unsigned long long seed, unsigned long long* stamps, float* sink)
-{
-    using namespace hwk;
-    unsigned long long t0 = 0;
-    if (threadIdx.x == 0) t0 = __builtin_amdgcn_s_memrealtime();
-    const PhiloxKey key = philox_key(seed);
-    PhiloxKey vkey = key;
-    philox_key_to_vgprs(vkey);
-    PhiloxPath pp[1] = {philox_path(key, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x)};
-    float y[1] = {0.0f}, S[1] = {0.0f};
-    ou_walk<float, 1>(vkey, pp, n_steps, e, y, S);
-    if (y[0] == 123.456f) sink[0] = S[0];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        stamps[2 * blockIdx.x] = t0;
-        stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-    }
-}
-
+// The PRODUCTION kernels are launched (hwk::zbc_superposed_kernel<float,1,1> or hwk::zcb_curve_blocked_kernel<P>) with
+// their optional `stamps` argument set; the engine itself always passes nullptr there.
+//   timeline_probe [log2 pairs = 20] [threads per workgroup = 512] [kernel = zbc | zcb1 | zcb2 | zcb4] [n_mat = 101]
 int main(int argc, char** argv)
 {
-    const int log2n = argc > 1 ? atoi(argv[1]) : 20, block = argc > 2 ? atoi(argv[2]) : 512, n_steps = argc > 3 ? atoi(argv[3]) : 500;
-    const int grid = (int)(((long long)1 << log2n) / block);
+    using namespace hwk;
+    const int log2n = argc > 1 ? atoi(argv[1]) : 20, block = argc > 2 ? atoi(argv[2]) : 512;
+    const std::string kern = argc > 3 ? argv[3] : "zbc";
+    const int n_mat = argc > 4 ? atoi(argv[4]) : 101;
+    const int P = kern == "zcb2" ? 2 : kern == "zcb4" ? 4 : 1;
+    const long long n_pairs = 1ll << log2n;
+    const int grid = (int)(n_pairs / ((long long)block * P));
+    const int n_steps = kern == "zbc" ? 500 : 1000;
     unsigned long long* d_st;
-    float* d_sink;
+    double *d_partials, *d_out;
     CHECK(hipMalloc(&d_st, (size_t)grid * 16));
-    CHECK(hipMalloc(&d_sink, 4));
+    CHECK(hipMalloc(&d_partials, (size_t)grid * (kern == "zbc" ? 5 : n_mat) * sizeof(double)));
+    CHECK(hipMalloc(&d_out, 1024 * sizeof(double)));
+    const float e = 0.99004983f;
+    ZbcArgs<float, 1> za{};
+    za.n_pairs = n_pairs; za.seed = 1; za.n_steps = n_steps; za.iters = 1; za.e = e;
+    za.sc[0].cz = 1.7e-4f; za.sc[0].cw = 1.67e-2f; za.sc[0].D0 = 0.93f; za.sc[0].P0 = 0.9f; za.sc[0].K = 0.9048374f;
+    za.blocks_per_run = (uint32_t)grid;
+    ZcbBlockedArgs ca{};
+    ca.n_pairs = n_pairs; ca.seed = 1; ca.n_steps = n_steps; ca.n_mat = n_mat; ca.stride = n_steps / (n_mat - 1); ca.iters = 1;
+    ca.e = e; ca.e2 = e * e; ca.c1 = 1.7e-2f; ca.c2 = 1.7e-2f;
+    const size_t lds = (size_t)(block / 64) * maturity_groups(n_mat) * kWave * sizeof(double);
+    auto launch = [&](unsigned long long seed, unsigned long long* stamps) {
+        if (kern == "zbc") {
+            za.seed = seed; za.stamps = stamps;
+            hipLaunchKernelGGL((zbc_superposed_kernel<float, 1, 1>), dim3(grid), dim3(block), 0, 0, za, d_partials, (unsigned*)nullptr, d_out);
+        } else {
+            ca.seed = seed; ca.stamps = stamps;
+            if (P == 4) hipLaunchKernelGGL(zcb_curve_blocked_kernel<4>, dim3(grid), dim3(block), lds, 0, ca, d_partials);
+            else if (P == 2) hipLaunchKernelGGL(zcb_curve_blocked_kernel<2>, dim3(grid), dim3(block), lds, 0, ca, d_partials);
+            else hipLaunchKernelGGL(zcb_curve_blocked_kernel<1>, dim3(grid), dim3(block), lds, 0, ca, d_partials);
+        }
+    };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 600; i++) hipLaunchKernelGGL(probe_kernel, dim3(grid), dim3(block), 0, 0, n_steps, 0.99f, 1ull, d_st, d_sink);   // clocks up
+    for (int i = 0; i < (kern == "zbc" ? 600 : 300); i++) launch(1ull, nullptr);   // clocks up
     CHECK(hipDeviceSynchronize());
+    float ms_plain = 1e9f, ms = 0.0f;
+    for (int i = 0; i < 5; i++) {                                                  // the same launch without stamps
+        CHECK(hipEventRecord(e0));
+        launch(2ull, nullptr);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float t;
+        CHECK(hipEventElapsedTime(&t, e0, e1));
+        ms_plain = std::min(ms_plain, t);
+    }
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL(probe_kernel, dim3(grid), dim3(block), 0, 0, n_steps, 0.99f, 2ull, d_st, d_sink);
+    launch(2ull, d_st);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
-    float ms;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
+    CHECK(hipGetLastError());
     std::vector<unsigned long long> st(2 * (size_t)grid);
     CHECK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
     unsigned long long base = ~0ull;
@@ -60,8 +82,9 @@ int main(int argc, char** argv)
     std::vector<double> s2 = start, e2 = end, l2 = life;
     std::sort(s2.begin(), s2.end()); std::sort(e2.begin(), e2.end()); std::sort(l2.begin(), l2.end());
     auto pct = [&](const std::vector<double>& v, double p) { return v[(size_t)(p * (v.size() - 1))]; };
-    printf("2^%d pairs, %d-thread workgroups (%d), %d steps; hipEvent time of the launch %.1f us (stamps: us after the first workgroup started)\n",
-           log2n, block, grid, n_steps, ms * 1e3);
+    printf("%s: 2^%d pairs, %d-thread workgroups (%d), %d steps, %d maturities; hipEvent time of the launch %.1f us (%.1f without stamps); "
+           "in-kernel span first start -> last end %.1f us (stamps: us after the first workgroup started)\n",
+           kern.c_str(), log2n, block, grid, n_steps, kern == "zbc" ? 0 : n_mat - 1, ms * 1e3, ms_plain * 1e3, e2.back());
     printf("workgroup START : min %.1f  p10 %.1f  p50 %.1f  p90 %.1f  max %.1f\n", s2[0], pct(s2, .1), pct(s2, .5), pct(s2, .9), s2.back());
     printf("workgroup END   : min %.1f  p10 %.1f  p50 %.1f  p90 %.1f  max %.1f\n", e2[0], pct(e2, .1), pct(e2, .5), pct(e2, .9), e2.back());
     printf("workgroup LIFE  : min %.1f  p10 %.1f  p50 %.1f  p90 %.1f  max %.1f\n", l2[0], pct(l2, .1), pct(l2, .5), pct(l2, .9), l2.back());
@@ -72,5 +95,13 @@ int main(int argc, char** argv)
            "workgroups alive in the last 5 / 10 / 20 us: %d / %d / %d of %d slots\n", s2.back(), e2.back(), e2.back() - s2.back(),
            (int)(e2.end() - std::lower_bound(e2.begin(), e2.end(), e2.back() - 5.0)), (int)(e2.end() - std::lower_bound(e2.begin(), e2.end(), e2.back() - 10.0)),
            (int)(e2.end() - std::lower_bound(e2.begin(), e2.end(), e2.back() - 20.0)), first_round);
+    printf("workgroups alive at 5 %% steps of the span:");
+    for (int k = 0; k <= 20; k++) {
+        const double t = e2.back() * k / 20.0;
+        int alive = 0;
+        for (int b = 0; b < grid; b++) alive += start[b] <= t && end[b] > t;
+        printf(" %d", alive);
+    }
+    printf("\n");
     return 0;
 }
