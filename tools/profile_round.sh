@@ -9,7 +9,7 @@ rm -rf "$OUT"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --spinup-ms 200 --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --spinup-ms 200 --no-cpu-baseline --no-extras"
 echo "rocprofv3 <--kernel-trace --stats | --pmc ...> -- $BENCH" | sed "s#$ROOT/##" > "$OUT/command.txt"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"

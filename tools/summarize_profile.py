@@ -66,6 +66,35 @@ def main():
             "note": "chip_time_per_launch = union of the dispatch intervals / launches: with two queues in flight a "
                     "dispatch lasts about twice as long as it occupies the chip for",
         }
+    # the bench JSON line printed BY THE TRACED PROCESS itself (default command and --streams 1): laid beside the
+    # kernel-trace figures of the same process so that ms_per_step, kernel_ms_avg and the trace can be compared
+    for key, log, dst in (("traced_default_run", "trace.log", "%s_bench_traced_default.json"), ("traced_streams1_run", "trace_s1.log", "%s_bench_traced_streams1.json")):
+        path = os.path.join(src, log)
+        if not os.path.exists(path):
+            continue
+        lines = [l for l in open(path, errors="replace").read().splitlines() if l.startswith('{"metric"')]
+        if not lines:
+            continue
+        with open(os.path.join(root, "profiles", dst % tag), "w") as fh:
+            fh.write(lines[-1] + "\n")
+        d = json.loads(lines[-1])
+        out[key] = {"file": "profiles/" + dst % tag, "value": d["value"], "ms_per_step": d["ms_per_step"],
+                    "value_spread": d.get("value_spread"),
+                    "kernel_ms_avg_isolated_hip_events": d["roofline"]["kernel_ms_avg"],
+                    "kernel_ms_per_step_in_timed_region": d["roofline"].get("kernel_ms_per_step_in_timed_region"),
+                    "serial_ms_per_step": d["serial"]["ms_per_step"],
+                    "note": "numbers of the process rocprofv3 was tracing (tracing itself costs a few per cent)"}
+    if "traced_default_run" in out and "kernel_trace" in out:
+        out["consistency"] = {
+            "default_run": {"ms_per_step_bench": out["traced_default_run"]["ms_per_step"],
+                            "chip_time_per_launch_ms_trace": out["kernel_trace"]["chip_time_per_launch_us"] / 1e3,
+                            "note": "the trace covers warm-up, stream selection and side measurements too; the union per launch is the "
+                                    "comparable figure (<= ms_per_step when the timed region is representative)"}}
+        if "single_stream_run" in out and "traced_streams1_run" in out:
+            out["consistency"]["streams1_run"] = {
+                "kernel_ms_avg_bench_hip_events": out["traced_streams1_run"]["kernel_ms_avg_isolated_hip_events"],
+                "kernel_avg_ms_trace": out["single_stream_run"]["avg_duration_us"] / 1e3,
+                "serial_ms_per_step_bench": out["traced_streams1_run"]["serial_ms_per_step"]}
     for pas in ("pmc_sq", "pmc_fetch", "pmc_write"):
         f = newest(os.path.join(src, pas, "**", "*counter_collection.csv"))
         if not f:
