@@ -65,6 +65,59 @@ def test_zbc_f32_hot_loop_keeps_its_instruction_budget(listing):
     assert all(c["v_mad_u64_u32"] <= 17 for c in loops)
 
 
+def test_zbc_f64_hot_loop_keeps_its_instruction_budget(listing):
+    """The double stepper in the (y, W) block form: per Philox block 3 v_cvt_f64_f32 + 2 v_fma(c)_f64 + 1 v_add_f64 (the
+    per-step form it replaced had 4 + 4 + 4), the same 16 multiplies, 8 transcendentals and 4 conversions as the float
+    loop, and at most 30 single-rate instructions: bench.py's VALU_MODEL["superposed_f64"] = 30 / 26 / 8."""
+    lines, meta = _kernel(listing, "zbc_superposed_kernelIdLi1ELi1E")
+    # 64 VGPRs, but 106 SGPRs (the double constants take two each): 7 waves per SIMD.  Measured at the issue bound all
+    # the same (0.204 ms at 2^20 pairs = the float kernel's 0.187 ms x 228 / 208 model cycles).
+    assert meta["ScratchSize"] == 0 and meta["Occupancy"] >= 7 and meta["NumVgprs"] <= 64
+    loops = _hot_loops(lines)
+    best = min(loops, key=lambda c: (c["v_mad_u64_u32"], sum(v for k, v in c.items() if k.startswith("v_"))))
+    trans = ("v_log_f32_e32", "v_sqrt_f32_e64", "v_sqrt_f32_e32", "v_sin_f32_e32", "v_cos_f32_e32")
+    f64 = {k: v for k, v in best.items() if "f64" in k}
+    assert best["v_mad_u64_u32"] == 16 and sum(best[t] for t in trans) == 8 and best["v_cvt_f32_u32_e32"] == 4
+    assert best["v_cvt_f64_f32_e32"] == 3, f64
+    assert best["v_fmac_f64_e32"] + best["v_fma_f64"] == 2 and best["v_add_f64"] == 1, f64
+    half = 16 + 4 + 3 + 2 + 1
+    valu = sum(v for k, v in best.items() if k.startswith("v_"))
+    assert valu - half - 8 <= 30, (valu, dict(best))         # single-rate rest: 30 today
+
+
+def test_curve_kernel_reduces_sixteen_maturities_together(listing):
+    """The blocked float curve kernel: no LDS traffic and no wave-wide reduction per maturity -- the transposed tree
+    (MaturityTree) spends 2 v_cndmask + 1 v_add_f32_dpp per merge, four merge levels in the loop body, the pending
+    vectors updated in place (no v_mov storm around the asm: at most 6 v_mov in the whole loop body of the P = 1 kernel),
+    and exactly one pair of v_exp_f32 per half-block event."""
+    lines, meta = _kernel(listing, "zcb_curve_blocked_kernelILi1E")
+    assert meta["ScratchSize"] == 0 and meta["Occupancy"] == 8 and meta["NumVgprs"] <= 56
+    body = [l.strip().split()[0] for l in lines if l.strip() and not l.strip().startswith((";", "."))]
+    c = Counter(body)
+    assert c["v_add_f32_dpp"] == 12                           # 4 levels x (2 copies of the loop: uniform high word or not, + the tail that completes the last group)
+    assert c["v_exp_f32_e32"] + c["v_exp_f32_e64"] == 8       # 2 events x 2 exponentials x 2 copies
+    loops = _hot_loops_with_branches(lines)
+    assert loops and all(l["v_mov_b32_e32"] + l["v_mov_b32"] <= 6 for l in loops), loops
+
+
+def _hot_loops_with_branches(lines):
+    """Loop bodies (back edge to a label >= 150 lines earlier) that contain the Philox multiplies."""
+    labels = {}
+    for i, l in enumerate(lines):
+        mm = re.match(r"^(\.LBB\d+_\d+):", l.strip())
+        if mm:
+            labels[mm.group(1)] = i
+    out = []
+    for i, l in enumerate(lines):
+        mm = re.search(r"s_c?branch\w* (\.LBB\d+_\d+)", l)
+        if mm and mm.group(1) in labels and 150 < i - labels[mm.group(1)] < 400:
+            ins = [x.strip().split()[0] for x in lines[labels[mm.group(1)]:i + 1] if x.strip() and not x.strip().startswith((";", "."))]
+            c = Counter(ins)
+            if 14 <= c["v_mad_u64_u32"] <= 18:
+                out.append(c)
+    return out
+
+
 def test_other_kernels_have_no_scratch_and_full_occupancy(listing):
     for pat in ("vega_pathwise_kernelIfLi1E", "zcb_curve_blocked_kernelILi1E", "zcb_curve_blocked_kernelILi2E",
                 "zbc_superposed_kernelIfLi2ELi1E", "zbc_reference_kernelILi0E"):
