@@ -446,6 +446,43 @@ def test_zcb_curve_blocked_kernel_variants(hwmc_mod, oracle_mod, monkeypatch):
     e5.close()
 
 
+@pytest.mark.parametrize("n_mat,n_steps", [(2, 1000), (3, 8), (11, 1000), (16, 60), (17, 64), (18, 68), (32, 124), (33, 1024),
+                                           (51, 1000), (101, 4000), (126, 1000), (251, 1000)])
+def test_zcb_curve_maturity_counts(hwmc_mod, oracle_mod, monkeypatch, n_mat, n_steps):
+    """The blocked float kernel reduces maturities sixteen at a time (MaturityTree): group boundaries at 16, 32, ...,
+    a partial last group completed with zero vectors, a single maturity, a group that ends exactly on the last one.
+    Every maturity count against the oracle (1e-5) and against the per-step kernel with its per-maturity slots; P = 1, 2
+    and 4 pairs per thread (HWMC_CURVE_P) on a ragged pair count; two passes through one workgroup (grid cap)."""
+    p = hwmc_mod.default_params("readme", n_steps=n_steps, n_mat=n_mat)
+    o = oracle_mod.Oracle("readme", n_steps=n_steps, n_mat=n_mat)
+    n = 1500 + n_mat                                                   # ragged: not a multiple of 64
+    want = o.zcb_curve(n, 17)
+    assert want.shape == (n_mat,) and want[0] == 2.0 * n
+    for P in ("1", "2", "4"):
+        monkeypatch.setenv("HWMC_CURVE_P", P)
+        with hwmc_mod.HullWhiteEngine(p, device=0) as e:
+            got = e.simulate_zcb(n, 17)
+            np.testing.assert_allclose(got, want, rtol=REL_F32, err_msg="P=%s" % P)
+            e.set_launch(block_size=64, max_blocks_per_cu=0)           # one wave per workgroup
+            np.testing.assert_allclose(e.simulate_zcb(n, 17), want, rtol=REL_F32)
+            # a capped grid: every thread walks several paths, the tree is re-armed between them
+            e.set_launch(block_size=128, max_blocks_per_cu=1)
+            cap = e.device_info()["compute_units"] * 128
+            big = 2 * cap * int(P) + 333
+            got_big = e.simulate_zcb(big, 5)
+            assert got_big[0] == 2.0 * big
+            halves = e.simulate_zcb(cap * int(P), 5) + e.simulate_zcb(big - cap * int(P), 5, path_offset=cap * int(P))
+            np.testing.assert_allclose(got_big[1:], halves[1:], rtol=1e-6)
+    monkeypatch.delenv("HWMC_CURVE_P")
+    monkeypatch.setenv("HWMC_CURVE_GENERIC", "1")
+    with hwmc_mod.HullWhiteEngine(p, device=0) as g:
+        np.testing.assert_allclose(g.simulate_zcb(n, 17), want, rtol=REL_F32)
+    pd = hwmc_mod.default_params("readme", n_steps=n_steps, n_mat=n_mat, precision="f64")
+    od = oracle_mod.Oracle("readme", n_steps=n_steps, n_mat=n_mat, precision="f64")
+    with hwmc_mod.HullWhiteEngine(pd, device=0) as d:
+        np.testing.assert_allclose(d.simulate_zcb(n, 17), od.zcb_curve(n, 17), rtol=REL_F64)
+
+
 def test_full_size_properties_of_the_multi_gpu_shares(setup, hwmc_mod):
     """One GPU's share of BASELINE configs[3] (2^24 pairs over 8 GPUs -> 2^21 per GPU) and configs[4] (2^26 pairs x
     4000-step grid over 8 GPUs -> 2^23 per GPU, f32 vs f64): the oracle cannot follow at these sizes in seconds, so
