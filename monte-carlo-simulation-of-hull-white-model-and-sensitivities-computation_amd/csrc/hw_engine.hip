@@ -228,7 +228,7 @@ int finish_columns(hw_ctx* c, hipStream_t st, int rows, int ncol, double* d_out,
 {
     if (c->single_launch && n_groups == 1) return HW_OK;
     hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(ncol * n_groups), dim3(256), 0, st, (const double*)c->d_partials, rows,
-                       1, rows * n_groups, (const double*)nullptr, -1.0, d_out, ncol);
+                       ncol, 1, (const double*)nullptr, -1.0, d_out, ncol);
     HIP_TRY(hipGetLastError());
     return HW_OK;
 }

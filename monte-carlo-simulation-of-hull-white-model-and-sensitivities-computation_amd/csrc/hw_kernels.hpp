@@ -629,7 +629,9 @@ __device__ __forceinline__ void grid_sum_finish(double (&v)[N], double* smem /*[
         if (lane < N) {
             double t = 0.0;
             for (int w = 0; w < nwaves; w++) t += smem[w * N + lane];
-            double* dst = partials + (size_t)lane * gridDim.x + blockIdx.x;      // column-major: [N][grid]
+            // row-major [grid][N]: the N doubles of a workgroup are contiguous (40 B for the five moments = two 32-byte
+            // sectors; the column-major layout of round 1 dirtied one sector per value: WRITE_SIZE 320 KB for 82 KB)
+            double* dst = partials + (size_t)blockIdx.x * N + lane;
             if (ticket == nullptr) *dst = t;
             else __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(t),
                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -662,7 +664,7 @@ __device__ __forceinline__ void grid_sum_finish(double (&v)[N], double* smem /*[
     for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            const unsigned long long bits = __hip_atomic_load(reinterpret_cast<unsigned long long*>(partials + (size_t)k * gridDim.x + b),
+            const unsigned long long bits = __hip_atomic_load(reinterpret_cast<unsigned long long*>(partials + (size_t)b * N + k),
                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             acc[k] += __longlong_as_double((long long)bits);
         }
@@ -683,8 +685,8 @@ __device__ __forceinline__ void grid_sum_finish(double (&v)[N], double* smem /*[
 
 // Second (tiny) launch: out[g*ncol + k] = scale[k] * sum_{b < nrows} partials[(g*nrows + b)*row_stride + k*col_stride],
 // fixed order; grid = ncol * n_groups workgroups (n_groups > 1: several runs finished by one launch).
-// The moment kernels store column-major ([N][grid]: row_stride 1, col_stride grid -> coalesced reads here),
-// the curve kernel row-major ([grid][n_mat]: its 101-wide rows are written coalesced instead).
+// All path kernels store row-major ([grid][N] for the moments, [grid][n_mat] for the curve: row_stride N, col_stride 1):
+// a workgroup's row is written as one contiguous piece; the strided reads here are served by the L2.
 // grid = ncol workgroups of 256 threads.  fix0: if >= 0, out[0] is overwritten with that value
 // (P_sum[0] = 2 N of market_data.cuh:76-78, done without the reference's write race).
 __global__ void finalize_columns_kernel(const double* __restrict__ partials, int nrows, int row_stride, int col_stride,

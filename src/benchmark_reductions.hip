@@ -171,7 +171,7 @@ int main(int argc, char** argv)
             case WAVE_SHUFFLE: hipLaunchKernelGGL(zbc_bench_kernel<WAVE_SHUFFLE>, dim3(grid), dim3(block), 0, 0, a, d_acc, d_partials, d_ticket, d_out); break;
             case DPP_PARTIALS:
                 hipLaunchKernelGGL(zbc_bench_kernel<DPP_PARTIALS>, dim3(grid), dim3(block), 0, 0, a, d_acc, d_partials, d_ticket, d_out);
-                hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(5), dim3(256), 0, 0, (const double*)d_partials, grid, 1, grid,
+                hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(5), dim3(256), 0, 0, (const double*)d_partials, grid, 5, 1,
                                    (const double*)nullptr, -1.0, d_out, 5);
                 break;
             default: hipLaunchKernelGGL(zbc_bench_kernel<DPP_TICKET>, dim3(grid), dim3(block), 0, 0, a, d_acc, d_partials, d_ticket, d_out); break;
