@@ -1239,6 +1239,39 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
     const int64_t T = (int64_t)gridDim.x * blockDim.x;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int nblk = a.n_steps >> 2, half_stride = a.stride >> 1;
+    // e^2 multiplies y twice per block next to a VGPR partner (v_pk_fma_f32 {e2, s1} x {y, b1}): held in a vector
+    // register it needs no v_mov per block to build that pair
+#ifndef HWK_CURVE_E2_VGPR
+#define HWK_CURVE_E2_VGPR 1
+#endif
+#ifndef HWK_CURVE_SKIP_LIVE
+#define HWK_CURVE_SKIP_LIVE 0     // 1: a copy of the time loop without the dead-slot mask for waves that have none (A/B: no gain)
+#endif
+#ifndef HWK_CURVE_C_VGPR
+#define HWK_CURVE_C_VGPR 1        // c1, c2 of z = c1 W - c2 y in vector registers too (measured -0.6 %)
+#endif
+#ifndef HWK_CURVE_E_VGPR
+#define HWK_CURVE_E_VGPR 0
+#endif
+#if HWK_CURVE_E2_VGPR
+    float e2v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(e2v) : "s"(a.e2));
+#else
+    const float e2v = a.e2;
+#endif
+#if HWK_CURVE_C_VGPR
+    float c1v, c2v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c1v) : "s"(a.c1));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c2v) : "s"(a.c2));
+#else
+    const float c1v = a.c1, c2v = a.c2;
+#endif
+#if HWK_CURVE_E_VGPR
+    float ev;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(ev) : "s"(a.e));
+#else
+    const float ev = a.e;
+#endif
 
     for (int it = 0; it < a.iters; it++) {
         PhiloxPath pp[P];
@@ -1256,17 +1289,26 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
         bool uhi = true;
 #pragma unroll
         for (int q = 0; q < P; q++) uhi = philox_uniform_hi(pp[q], a2s[q]) && uhi;
+        // Dead slots (pair index >= n_pairs) exist only in the last, ragged pass of the last workgroups; their contributions are
+        // multiplied by live = 0.  Experiments (profiles/r02_curve_ab.txt): skipping that multiply for waves without dead
+        // slots through a second copy of the loop (HWK_CURVE_SKIP_LIVE=1) measured no faster (0.3926 vs 0.3909 ms), and a
+        // per-maturity scalar branch around it 2 % slower.
+        bool any_dead = false;
+#pragma unroll
+        for (int q = 0; q < P; q++) any_dead = any_dead || __builtin_amdgcn_ballot_w64(live[q] == 0.0f) != 0;
         HWK_SETPRIO(1);
-        auto blocks = [&](auto tag) {
+        auto blocks = [&](auto tag, auto masked_tag) {
             constexpr bool UHI = decltype(tag)::value;
+            constexpr bool MASKED = decltype(masked_tag)::value;
             int to_event = half_stride, m = 0;         // half blocks until the next maturity
             for (int j = 0; j < nblk; j++) {
                 const int ev = to_event <= 2 ? to_event : 0;               // 1: after the first half, 2: after the second
                 float accq;                                                // assigned by q == 0 of an event block
                 auto contribute = [&](int q) {
-                    const float z = __builtin_fmaf(a.c1, W[q], -a.c2 * y[q]);
+                    const float z = __builtin_fmaf(c1v, W[q], -c2v * y[q]);
                     const float c = hw_exp2(z) + hw_exp2(-z);              // market_data.cuh:60
-                    accq = q == 0 ? live[q] * c : __builtin_fmaf(live[q], c, accq);
+                    if constexpr (MASKED) accq = q == 0 ? live[q] * c : __builtin_fmaf(live[q], c, accq);
+                    else accq = q == 0 ? c : accq + c;
                 };
 #pragma unroll
                 for (int q = 0; q < P; q++) {
@@ -1275,7 +1317,7 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
                     float s0, sn0, cs0, s1, sn1, cs1;
                     box_muller_parts(w0, w1, s0, sn0, cs0);
                     box_muller_parts(w2, w3, s1, sn1, cs1);
-                    y[q] = __builtin_fmaf(a.e2, y[q], s0 * __builtin_fmaf(a.e, sn0, cs0));
+                    y[q] = __builtin_fmaf(e2v, y[q], s0 * __builtin_fmaf(ev, sn0, cs0));
                     W[q] = __builtin_fmaf(s0, sn0 + cs0, W[q]);
                     // ev is wave-uniform: these are scalar branches.  The empty volatile asm keeps the compiler from
                     // if-converting them (it did: both pairs of v_exp_f32 ran in every event block and a v_cndmask
@@ -1284,7 +1326,7 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
                         asm volatile("" ::: "memory");
                         contribute(q);
                     }
-                    y[q] = __builtin_fmaf(a.e2, y[q], s1 * __builtin_fmaf(a.e, sn1, cs1));
+                    y[q] = __builtin_fmaf(e2v, y[q], s1 * __builtin_fmaf(ev, sn1, cs1));
                     W[q] = __builtin_fmaf(s1, sn1 + cs1, W[q]);
                     if (ev == 2) {
                         asm volatile("" ::: "memory");
@@ -1296,8 +1338,16 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
                 to_event = ev ? half_stride - (2 - ev) : to_event - 2;
             }
         };
-        if (uhi) blocks(std::true_type{});
-        else blocks(std::false_type{});
+#if HWK_CURVE_SKIP_LIVE
+        if (!any_dead) {
+            if (uhi) blocks(std::true_type{}, std::false_type{});
+            else blocks(std::false_type{}, std::false_type{});
+        } else
+#endif
+        {
+            if (uhi) blocks(std::true_type{}, std::true_type{});
+            else blocks(std::false_type{}, std::true_type{});
+        }
         HWK_SETPRIO(0);
         slots.finish(a.n_mat);
     }
