@@ -16,7 +16,7 @@ all: q1 q2 q3
 lib: $(LIB)
 
 $(LIB): $(PKG)/csrc/hw_engine.hip $(PKG)/csrc/hw_kernels.hpp $(PKG)/csrc/hw_model.hpp include/hw_mc.h
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $(PKG)/csrc/hw_engine.hip -o $@
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -Wshadow -fPIC -shared $(PKG)/csrc/hw_engine.hip -o $@
 
 q1: $(SRC)/1_bond_pricing.cpp $(SRC)/hw_app.hpp $(LIB)
 	@mkdir -p $(BIN) data plots

@@ -1248,7 +1248,7 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
 #define HWK_CURVE_SKIP_LIVE 0     // 1: a copy of the time loop without the dead-slot mask for waves that have none (A/B: no gain)
 #endif
 #ifndef HWK_CURVE_C_VGPR
-#define HWK_CURVE_C_VGPR 1        // c1, c2 of z = c1 W - c2 y in vector registers too (measured -0.6 %)
+#define HWK_CURVE_C_VGPR 0        // 1: c1, c2 of z = c1 W - c2 y in vector registers too (A/B: no gain)
 #endif
 #ifndef HWK_CURVE_E_VGPR
 #define HWK_CURVE_E_VGPR 0
@@ -1267,10 +1267,10 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
     const float c1v = a.c1, c2v = a.c2;
 #endif
 #if HWK_CURVE_E_VGPR
-    float ev;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(ev) : "s"(a.e));
+    float e1v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(e1v) : "s"(a.e));
 #else
-    const float ev = a.e;
+    const float e1v = a.e;
 #endif
 
     for (int it = 0; it < a.iters; it++) {
@@ -1317,7 +1317,7 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
                     float s0, sn0, cs0, s1, sn1, cs1;
                     box_muller_parts(w0, w1, s0, sn0, cs0);
                     box_muller_parts(w2, w3, s1, sn1, cs1);
-                    y[q] = __builtin_fmaf(e2v, y[q], s0 * __builtin_fmaf(ev, sn0, cs0));
+                    y[q] = __builtin_fmaf(e2v, y[q], s0 * __builtin_fmaf(e1v, sn0, cs0));
                     W[q] = __builtin_fmaf(s0, sn0 + cs0, W[q]);
                     // ev is wave-uniform: these are scalar branches.  The empty volatile asm keeps the compiler from
                     // if-converting them (it did: both pairs of v_exp_f32 ran in every event block and a v_cndmask
@@ -1326,7 +1326,7 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
                         asm volatile("" ::: "memory");
                         contribute(q);
                     }
-                    y[q] = __builtin_fmaf(e2v, y[q], s1 * __builtin_fmaf(ev, sn1, cs1));
+                    y[q] = __builtin_fmaf(e2v, y[q], s1 * __builtin_fmaf(e1v, sn1, cs1));
                     W[q] = __builtin_fmaf(s1, sn1 + cs1, W[q]);
                     if (ev == 2) {
                         asm volatile("" ::: "memory");

@@ -483,6 +483,27 @@ def test_zcb_curve_maturity_counts(hwmc_mod, oracle_mod, monkeypatch, n_mat, n_s
         np.testing.assert_allclose(d.simulate_zcb(n, 17), od.zcb_curve(n, 17), rtol=REL_F64)
 
 
+def test_zcb_curve_blocked_equals_generic_at_full_size(hwmc_mod, oracle_mod, monkeypatch):
+    """The blocked float curve kernel (half Philox blocks, transposed reduction, P pairs per thread) against the per-step
+    kernel with its own reduction -- two independent evaluation orders of the same float arithmetic -- at every size class
+    up to BASELINE's 2^20 pairs and beyond (P = 1, 2, 4; 256- and 512-thread workgroups; ragged counts), and against
+    the oracle itself at 2^20 pairs (about a second of OpenMP work)."""
+    p = hwmc_mod.default_params("readme")
+    monkeypatch.setenv("HWMC_CURVE_GENERIC", "1")
+    g = hwmc_mod.HullWhiteEngine(p, device=0)
+    monkeypatch.delenv("HWMC_CURVE_GENERIC")
+    e = hwmc_mod.HullWhiteEngine(p, device=0)
+    for n in (1000, 1 << 17, (1 << 18) + 512, 1 << 19, 1 << 20, (1 << 20) + 77, 1 << 21, 1 << 22):
+        a, b = e.simulate_zcb(n, 99), g.simulate_zcb(n, 99)
+        assert a[0] == b[0] == 2.0 * n
+        np.testing.assert_allclose(a[1:], b[1:], rtol=2e-7, err_msg="n = %d" % n)
+    o = oracle_mod.Oracle("readme")
+    for sg in (0.099, 0.101):                                          # the two curves of the recalibrated FD (3_sens:449-525)
+        np.testing.assert_allclose(e.simulate_zcb(1 << 20, 99, sigma=sg), o.zcb_curve(1 << 20, 99, sigma=sg), rtol=REL_F32)
+    e.close()
+    g.close()
+
+
 def test_full_size_properties_of_the_multi_gpu_shares(setup, hwmc_mod):
     """One GPU's share of BASELINE configs[3] (2^24 pairs over 8 GPUs -> 2^21 per GPU) and configs[4] (2^26 pairs x
     4000-step grid over 8 GPUs -> 2^23 per GPU, f32 vs f64): the oracle cannot follow at these sizes in seconds, so

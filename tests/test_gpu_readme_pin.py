@@ -116,6 +116,12 @@ def test_variance_reduction_of_the_optimal_control_variate(setup):
     raw = np.array([r["mean_X"] for r in res])
     vr = 100.0 * (1.0 - adj.var(ddof=1) / raw.var(ddof=1))
     assert abs(vr - README["var_reduction_pct"]) < 12.0, vr
+    # the run-to-run standard deviation of the price, pinned far better by 200 runs than by 20: the README's CV of 0.0496 %
+    # is an sd of 1.76e-5 with a 16 % standard error of its own (19 degrees of freedom); 200 runs of the CPU oracle's
+    # restatement at 2^13 pairs, scaled by sqrt(2^13 / 2^20), give 2.04e-5 +- 6 %
+    sd = float(adj.std(ddof=1))
+    assert 1.7e-5 < sd < 2.4e-5, sd
+    assert abs(sd - 1.76e-5) < 3.0 * 0.16 * 1.76e-5                    # within 3 standard errors of the README's estimate
     # naive beta = 1 makes it WORSE (README.md:168: -42 %): the sign of that statement is checkable too
     naive = np.array([r["mean_X"] - 1.0 * (r["mean_Y"] - README["P10"]) for r in res])
     assert naive.var(ddof=1) > raw.var(ddof=1)

@@ -45,6 +45,7 @@ def main():
         adj = np.array([r["price"] for r in r2])
         raw = np.array([r["mean_X"] for r in r2])
         naive = np.array([r["mean_X"] - (r["mean_Y"] - 0.876844) for r in r2])
+        print("%-34s %.3e (CV %.4f %%)      1.76e-05 (CV 0.0496 %%, 20 runs)" % ("sd of a run's price, 200 runs", adj.std(ddof=1), 100 * adj.std(ddof=1) / adj.mean()))
         print("%-34s %+.1f %% (200 runs)            +20.4 %% (20 runs)" % ("variance reduction, beta*", 100 * (1 - adj.var(ddof=1) / raw.var(ddof=1))))
         print("%-34s %+.1f %% (200 runs)            -42 %%" % ("variance reduction, beta = 1", 100 * (1 - naive.var(ddof=1) / raw.var(ddof=1))))
         runs = e.simulate_sensitivity_runs(N, 4242, n_runs=20, seed_stride=982451653) / N
