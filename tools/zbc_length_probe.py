@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""ZBC path-kernel time at 2^20 pairs against the number of executed steps (S1 = 2.5, 5, 9.9 -> 250, 500, 990 steps): the
+straight line T = t0 + c * steps separates what a launch spends outside the time loop from the per-step rate AT THIS SIZE
+(the roof for the 1000-step curve kernel at the same size).    python tools/zbc_length_probe.py"""
 import sys, os, numpy as np
 sys.path.insert(0, os.getcwd())
 import hwmc
