@@ -216,11 +216,18 @@ int  hw_get_kernel_info(hw_ctx* ctx, const char* kernel /* "zbc" | "zbc_ref" | "
 /* ---- several GPUs in one process ---------------------------------------------------------------
  * (not in the reference, which is single-GPU).  A communicator spans contexts created on DIFFERENT
  * devices with identical parameters and market curves.  Each call shards the paths by global id
- * (context g gets a contiguous block), launches every device asynchronously and sums the results with
- * ONE grouped ncclAllReduce (RCCL over xGMI; librccl.so.1 is loaded at hw_comm_create, the library
- * itself does not link it).  wall_ms: host wall time from the first launch to the reduced result. */
+ * (context g gets a contiguous block); one persistent host thread per device (started by hw_comm_create)
+ * enqueues that device's shard and ONE ncclAllReduce on the device's stream (RCCL over xGMI; librccl.so.1 is
+ * loaded at hw_comm_create, the library itself does not link it) and waits for it.  wall_ms: host wall time from the first launch to the reduced result. */
 typedef struct hw_comm hw_comm;
 int  hw_comm_create(int32_t n, hw_ctx* const* ctxs, hw_comm** out);
+/* The same with a choice of how the shards' sums are combined: HW_COMM_RCCL (what hw_comm_create does) or
+ * HW_COMM_HOST_SUM -- no RCCL at all: every device's worker thread brings its sums to the host and the caller adds
+ * them in rank order (bit-reproducible).  In that mode the contexts may share a device, so the threaded dispatch can
+ * be rehearsed with G > 1 on a one-GPU box; it is also the fallback where librccl is not installed. */
+#define HW_COMM_RCCL      0
+#define HW_COMM_HOST_SUM  1
+int  hw_comm_create_ex(int32_t n, hw_ctx* const* ctxs, int32_t flags, hw_comm** out);
 void hw_comm_destroy(hw_comm* comm);
 int  hw_comm_zbc_moments(hw_comm* comm, const hw_zbc_request* req, double out[5], float* wall_ms);
 int  hw_comm_zcb_curve(hw_comm* comm, int64_t n_pairs, uint64_t seed, double sigma, double* P_sum, float* wall_ms);

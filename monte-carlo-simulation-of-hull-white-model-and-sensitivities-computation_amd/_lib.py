@@ -15,6 +15,7 @@ HW_F32, HW_F64 = 0, 1
 HW_TABLES_F64, HW_TABLES_REF_F32 = 0, 1
 HW_STEPPER_SUPERPOSED, HW_STEPPER_REFERENCE = 0, 1
 HW_DRIFT_BASE, HW_DRIFT_SHIFTED = 0, 1
+HW_COMM_RCCL, HW_COMM_HOST_SUM = 0, 1
 
 
 class HwParams(C.Structure):
@@ -83,6 +84,7 @@ SIGNATURES = {
                                          C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "hw_get_kernel_info": (C.c_int, [_CTX, C.c_char_p, C.POINTER(HwKernelInfo)]),
     "hw_comm_create": (C.c_int, [C.c_int32, C.POINTER(_CTX), C.POINTER(C.c_void_p)]),
+    "hw_comm_create_ex": (C.c_int, [C.c_int32, C.POINTER(_CTX), C.c_int32, C.POINTER(C.c_void_p)]),
     "hw_comm_destroy": (None, [C.c_void_p]),
     "hw_comm_zbc_moments": (C.c_int, [C.c_void_p, C.POINTER(HwZbcRequest), _DP, C.POINTER(C.c_float)]),
     "hw_comm_zcb_curve": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_double, _DP, C.POINTER(C.c_float)]),

@@ -1176,6 +1176,11 @@ struct hw_comm {
     const std::function<int(int)>* job = nullptr;
     std::vector<int> rc;
     std::vector<std::string> err;
+    // HW_COMM_HOST_SUM: no RCCL; every worker brings its shard's sums to its slot here and the caller adds the slots
+    // in rank order (deterministic).  Contexts may then share a device: the threaded dispatch can be rehearsed, G > 1,
+    // on a box with one GPU.
+    bool host_sum = false;
+    std::vector<double> host_slots;        // [G][kOutCap]
 };
 
 #define NCCL_TRY(cm, expr)                                                                              \
@@ -1259,27 +1264,54 @@ static int comm_run(hw_comm* cm, int64_t n_units, int count_out, double* out, fl
         comm_shard(n_units, g, G, &off, &cnt);
         int rc = enqueue(g, off, cnt, c->d_out, c->stream);
         if (rc) return rc;
-        // one communicator per thread: no group call needed (each rank's call comes from its own thread, as in the
-        // one-process-per-GPU layout)
-        NCCL_TRY(cm, cm->AllReduce(c->d_out, c->d_out, (size_t)count_out, ncclDouble, ncclSum, cm->comm[g], c->stream));
-        if (g == 0) HIP_TRY(hipMemcpyAsync(out, c->d_out, count_out * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (cm->host_sum) {
+            HIP_TRY(hipMemcpyAsync(&cm->host_slots[(size_t)g * kOutCap], c->d_out, count_out * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        } else {
+            // one communicator per thread: no group call needed (each rank's call comes from its own thread, as in the
+            // one-process-per-GPU layout)
+            NCCL_TRY(cm, cm->AllReduce(c->d_out, c->d_out, (size_t)count_out, ncclDouble, ncclSum, cm->comm[g], c->stream));
+            if (g == 0) HIP_TRY(hipMemcpyAsync(out, c->d_out, count_out * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        }
         HIP_TRY(hipStreamSynchronize(c->stream));
         free_retired(c);
         return HW_OK;
     };
     const int rc = comm_dispatch(cm, job);
+    if (rc == HW_OK && cm->host_sum)
+        for (int k = 0; k < count_out; k++) {
+            double t = 0.0;
+            for (int g = 0; g < G; g++) t += cm->host_slots[(size_t)g * kOutCap + k];       // rank order: reproducible
+            out[k] = t;
+        }
     if (wall_ms) *wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
 }
 
 extern "C" {
 
-int hw_comm_create(int32_t n, hw_ctx* const* ctxs, hw_comm** out)
+int hw_comm_create(int32_t n, hw_ctx* const* ctxs, hw_comm** out) { return hw_comm_create_ex(n, ctxs, HW_COMM_RCCL, out); }
+
+int hw_comm_create_ex(int32_t n, hw_ctx* const* ctxs, int32_t flags, hw_comm** out)
 {
     if (!out || !ctxs || n < 1 || n > 64) return fail(HW_E_INVALID, "bad argument");
+    if (flags != HW_COMM_RCCL && flags != HW_COMM_HOST_SUM) return fail(HW_E_INVALID, "unknown communicator flags %d", flags);
     *out = nullptr;
     hw_comm* cm = new (std::nothrow) hw_comm();
     if (!cm) return fail(HW_E_NOMEM, "out of host memory");
+    if (flags == HW_COMM_HOST_SUM) {
+        for (int i = 0; i < n; i++) {
+            if (!ctxs[i]) { delete cm; return fail(HW_E_INVALID, "null context %d", i); }
+            for (int j = 0; j < i; j++) if (ctxs[j] == ctxs[i]) { delete cm; return fail(HW_E_INVALID, "context %d listed twice", i); }
+            cm->ctx.push_back(ctxs[i]);
+        }
+        cm->host_sum = true;
+        cm->host_slots.assign((size_t)n * kOutCap, 0.0);
+        cm->rc.assign(n, 0);
+        cm->err.assign(n, std::string());
+        for (int g = 0; g < n; g++) cm->workers.emplace_back(comm_worker, cm, g);
+        *out = cm;
+        return HW_OK;
+    }
     cm->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!cm->lib) cm->lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!cm->lib) { delete cm; return fail(HW_E_HIP, "cannot load RCCL (librccl.so.1): %s", dlerror()); }
@@ -1324,7 +1356,7 @@ void hw_comm_destroy(hw_comm* cm)
     }
     cm->cv_job.notify_all();
     for (std::thread& t : cm->workers) t.join();
-    for (size_t i = 0; i < cm->comm.size(); i++) {
+    for (size_t i = 0; i < cm->comm.size(); i++) {      // (no communicators in HW_COMM_HOST_SUM mode)
         (void)hipSetDevice(cm->ctx[i]->device);
         (void)cm->CommDestroy(cm->comm[i]);
     }

@@ -342,12 +342,15 @@ class HullWhiteFleet:
     (hw_comm_*, include/hw_mc.h).  bench.py uses one process per GPU with torch.distributed instead
     (parallel.py); this class is what the q1/q2/q3 executables use for --gpus N."""
 
-    def __init__(self, engines):
+    def __init__(self, engines, host_sum=False):
+        """host_sum=True: no RCCL -- the per-device worker threads bring their sums to the host and the library adds
+        them in rank order (HW_COMM_HOST_SUM); the engines may then share a device (rehearsal on a one-GPU box)."""
         self.lib = L.load()
         self.engines = list(engines)
         arr = (C.c_void_p * len(self.engines))(*[e._ctx for e in self.engines])
         self._comm = C.c_void_p()
-        L.check(self.lib.hw_comm_create(len(self.engines), arr, C.byref(self._comm)))
+        L.check(self.lib.hw_comm_create_ex(len(self.engines), arr, L.HW_COMM_HOST_SUM if host_sum else L.HW_COMM_RCCL,
+                                           C.byref(self._comm)))
 
     def close(self):
         if self._comm:

@@ -414,6 +414,51 @@ def test_comm_one_device_equals_single_context(setup, hwmc_mod):
         hwmc_mod.HullWhiteFleet([e, e])                                             # one device twice
 
 
+def test_comm_threaded_dispatch_rehearsal_with_four_workers(hwmc_mod, oracle_mod):
+    """The per-device worker threads of hw_comm_* (one persistent host thread per context: spin, then sleep on a condition
+    variable; the job runs on the worker, its error text travels back) with G = 4 -- on ONE GPU, which the
+    HW_COMM_HOST_SUM mode allows: no RCCL, the four contexts share device 0, the library adds the four shards' sums in
+    rank order.  Every call must equal the four shard calls added in that order BIT FOR BIT, and the single-context sums
+    to 1e-13; 300 back-to-back calls (the spin path) and calls after a pause (the sleep path); errors raised on a worker
+    reach the caller with their text."""
+    import time
+    p = hwmc_mod.default_params("readme")
+    P, f = hwmc_mod.analytic_curve(p)
+    engines = [hwmc_mod.HullWhiteEngine(p, device=0) for _ in range(4)]
+    for e in engines:
+        e.load_market_data(P, f)
+    ref = engines[0]
+    try:
+        with hwmc_mod.HullWhiteFleet(engines, host_sum=True) as fleet:
+            for n in (1001, 50_001, 1 << 18, 3):                                        # 3 pairs over 4 workers: one gets none
+                got = fleet.simulate_ZBC_control_variate(n, 77)
+                shards = [hwmc_mod.parallel.shard(n, g, 4) for g in range(4)]
+                want = np.zeros(5)
+                for off, cnt in shards:                                                # rank order, as the library adds them
+                    want = want + ref.simulate_ZBC_control_variate(cnt, 77, path_offset=off)
+                assert np.array_equal(got, want), n
+                np.testing.assert_allclose(got, ref.simulate_ZBC_control_variate(n, 77), rtol=1e-13)
+            c = fleet.simulate_zcb(20_000, 5)
+            assert c[0] == 2.0 * 20_000
+            np.testing.assert_allclose(c[1:], ref.simulate_zcb(20_000, 5)[1:], rtol=1e-6)   # float row sums regroup with the shards
+            assert fleet.simulate_sensitivity(40_000, 9) == pytest.approx(ref.simulate_sensitivity(40_000, 9), rel=1e-13)
+            first = fleet.simulate_ZBC_control_variate(4096, 1)
+            for i in range(300):                                                       # back to back: workers never sleep
+                assert np.array_equal(fleet.simulate_ZBC_control_variate(4096, 1), first)
+            for pause in (0.002, 0.05, 0.3):                                           # longer than the 100 us spin: futex path
+                time.sleep(pause)
+                assert np.array_equal(fleet.simulate_ZBC_control_variate(4096, 1), first)
+            with pytest.raises(hwmc_mod.HwError) as ei:                                # S2 > T_final: rejected on the worker threads
+                fleet.simulate_ZBC_control_variate(4096, 1, S1=5.0, S2=11.0)
+            assert "device" in str(ei.value) and "S1 < S2" in str(ei.value)
+            assert np.array_equal(fleet.simulate_ZBC_control_variate(4096, 1), first)   # and the communicator still works
+        with pytest.raises(hwmc_mod.HwError):
+            hwmc_mod.HullWhiteFleet([engines[0], engines[0]], host_sum=True)           # the same context twice
+    finally:
+        for e in engines:
+            e.close()
+
+
 # ---- curve kernel variants ---------------------------------------------------------------------------
 def test_zcb_curve_blocked_kernel_variants(hwmc_mod, oracle_mod, monkeypatch):
     """The float curve runs a blocked kernel (half Philox blocks, P pairs per thread: P = 1 below 2^21 pairs, 2
