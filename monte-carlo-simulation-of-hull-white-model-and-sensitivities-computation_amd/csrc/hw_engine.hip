@@ -146,8 +146,10 @@ void free_retired(hw_ctx* c)          // caller guarantees that nothing enqueued
 int use_stream(hw_ctx* c, hipStream_t st)
 {
     if (c->have_last_stream && c->last_stream != st) {
-        HIP_TRY(hipEventRecord(c->ev_switch, c->last_stream));       // everything enqueued so far on the old stream
-        HIP_TRY(hipStreamWaitEvent(st, c->ev_switch, 0));
+        // everything enqueued so far on the old stream.  If the caller has destroyed that stream in the meantime the record
+        // fails; hipStreamDestroy completes a stream's work first, so there is nothing left to wait for.
+        if (hipEventRecord(c->ev_switch, c->last_stream) == hipSuccess) HIP_TRY(hipStreamWaitEvent(st, c->ev_switch, 0));
+        else (void)hipGetLastError();
     }
     c->last_stream = st;
     c->have_last_stream = true;
