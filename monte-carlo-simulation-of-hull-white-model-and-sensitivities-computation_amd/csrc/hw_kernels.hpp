@@ -1072,6 +1072,22 @@ zbc_reference_kernel(const ZbcRefArgs a, const float* __restrict__ drift, double
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     constexpr float kLog2e = 1.4426950408889634f;
     const float half_dt = 0.5f * a.dt;                  // exact (power-of-two scaling)
+    // sig_st in a vector register: d + sig_st g contracts to v_fma(sig_st, g, d) with the wave-uniform drift d as its one
+    // scalar operand; with sig_st scalar too, every step paid a v_mov to bring d into a vector register
+    float sig_v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(sig_v) : "s"(a.sig_st));
+#ifndef HWK_REF_STEPS_PRIO0
+#define HWK_REF_STEPS_PRIO0 0
+#endif
+#ifndef HWK_REF_E_VGPR
+#define HWK_REF_E_VGPR 0        // A/B: no gain
+#endif
+#if HWK_REF_E_VGPR
+    float e_v;                                           // likewise e: the packed r' = r e + t takes {e, e} from registers
+    asm volatile("v_mov_b32 %0, %1" : "=v"(e_v) : "s"(a.e));
+#else
+    const float e_v = a.e;
+#endif
 
     double acc[5] = {0, 0, 0, 0, 0};
     for (int it = 0; it < a.iters; it++) {
@@ -1083,24 +1099,43 @@ zbc_reference_kernel(const ZbcRefArgs a, const float* __restrict__ drift, double
         uint32_t a2s;
         const bool uhi = philox_uniform_hi(pp, a2s);                  // wave-uniform: scalar round-2 multiply
         HWK_SETPRIO(1);
+        auto step = [&](float d, float gc) {
+            const float sG = sig_v * gc;
+            const float r1n = __builtin_fmaf(r1, e_v, d + sG);               // common.cuh:241
+            I1 += (r1 + r1n) * half_dt;                                       // common.cuh:242; 0.5f*x*dt == x*(0.5f*dt) bit for bit
+            r1 = r1n;
+            const float r2n = __builtin_fmaf(r2, e_v, d - sG);
+            I2 += (r2 + r2n) * half_dt;
+            r2 = r2n;
+        };
         auto walk = [&](auto tag) {
             constexpr bool UHI = decltype(tag)::value;
-            for (int i = 0; i < a.n_steps; i += 4) {                 // common.cuh:325-332
-                float g[4];
+            const int nfull = a.n_steps & ~3;
+            for (int i = 0; i < nfull; i += 4) {                     // common.cuh:325-332, four steps (one Philox block) per trip:
+                float g[4];                                          // the four drifts come with ONE wave-uniform load
                 normal4_prio<UHI>(vkey, pp, a2s, (uint32_t)(i >> 2), g);
+                const float d0 = tab[i], d1 = tab[i + 1], d2 = tab[i + 2], d3 = tab[i + 3];
+#if HWK_REF_STEPS_PRIO0
+                asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]));
+                HWK_SETPRIO(0);
+                asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]));
+#endif
+                step(d0, g[0]);
+                step(d1, g[1]);
+                step(d2, g[2]);
+                step(d3, g[3]);
+#if HWK_REF_STEPS_PRIO0
+                asm volatile("" : "+v"(r1), "+v"(r2), "+v"(I1), "+v"(I2));
+                HWK_SETPRIO(1);
+                asm volatile("" : "+v"(r1), "+v"(r2), "+v"(I1), "+v"(I2));
+#endif
+            }
+            if (nfull < a.n_steps) {                                 // 1..3 remaining steps
+                float g[4];
+                normal4_prio<UHI>(vkey, pp, a2s, (uint32_t)(nfull >> 2), g);
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    if (i + c < a.n_steps) {
-                        const float d = tab[i + c];
-                        const float sG = a.sig_st * g[c];
-                        const float r1n = __builtin_fmaf(r1, a.e, d + sG);   // common.cuh:241
-                        I1 += (r1 + r1n) * half_dt;                           // common.cuh:242; 0.5f*x*dt == x*(0.5f*dt) bit for bit
-                        r1 = r1n;
-                        const float r2n = __builtin_fmaf(r2, a.e, d - sG);
-                        I2 += (r2 + r2n) * half_dt;
-                        r2 = r2n;
-                    }
-                }
+                for (int c = 0; c < 3; c++)
+                    if (nfull + c < a.n_steps) step(tab[nfull + c], g[c]);
             }
         };
         if (uhi) walk(std::true_type{});

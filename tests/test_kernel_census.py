@@ -118,6 +118,22 @@ def _hot_loops_with_branches(lines):
     return out
 
 
+def test_reference_stepper_loop_walks_a_whole_philox_block_per_trip(listing):
+    """zbc_reference_kernel (the reference's per-step arithmetic verbatim, both legs as a 2-vector): the four drifts of a
+    block come with ONE wave-uniform s_load_dwordx4 (the per-step version issued a scalar load + wait + bounds branch +
+    v_mov per step and ran 11 % slower), and the loop body holds 34 single-rate + 32 half-rate + 8 quarter-rate
+    instructions = bench.py's VALU_MODEL["reference"]."""
+    lines, meta = _kernel(listing, "zbc_reference_kernelILi0E")
+    assert meta["ScratchSize"] == 0 and meta["Occupancy"] == 8
+    loops = _hot_loops(lines)
+    best = min(loops, key=lambda c: (c["v_mad_u64_u32"], sum(v for k, v in c.items() if k.startswith("v_"))))
+    assert best["s_load_dwordx4"] == 1 and best["s_load_dword"] == 0
+    assert best["v_mad_u64_u32"] == 16 and best["v_pk_fma_f32"] == 8 and best["v_pk_add_f32"] == 4
+    assert best["v_mov_b32_e32"] + best["v_mov_b64_e32"] == 0
+    valu = sum(v for k, v in best.items() if k.startswith("v_"))
+    assert valu <= 74, (valu, dict(best))
+
+
 def test_other_kernels_have_no_scratch_and_full_occupancy(listing):
     for pat in ("vega_pathwise_kernelIfLi1E", "zcb_curve_blocked_kernelILi1E", "zcb_curve_blocked_kernelILi2E",
                 "zbc_superposed_kernelIfLi2ELi1E", "zbc_reference_kernelILi0E"):

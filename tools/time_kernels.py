@@ -43,8 +43,9 @@ def main():
         fn()
         ms = []
         for _ in range(a.reps):
-            e.profile_enable(1)
-            fn()
+            fn()                                    # back-to-back pair: the second launch is the timed one (a launch that
+            e.profile_enable(1)                     # follows tens of microseconds of idle time -- reading the events back --
+            fn()                                    # measured up to 15 % slower for the reference stepper)
             ms.append(float(e.profile_read(1)[0]))
         med = float(np.median(ms))
         units = paths if "vega pathwise" in name else paths // 2
