@@ -1238,9 +1238,9 @@ zcb_curve_kernel(const ZcbArgs<REAL> a, double* __restrict__ partials)
 //   * the steps advance half a Philox block (= one Box-Muller pair = 2 steps) at a time in the (y, W) form of
 //     ou_walk: 5 single-rate ops per two steps instead of 6, and a maturity (every stride/2 half blocks) always
 //     falls on a half-block boundary;  z = cz (S - y/2) = c1 W - c2 y with c1 = cz/(1-e), c2 = cz (e/(1-e) + 1/2);
-//   * every thread carries P pairs through the time loop together, so the per-maturity wave reduction and LDS
-//     update (6 DPP adds + an LDS read-modify-write, ~50 of the ~85 issue cycles a maturity costs a wave) is paid
-//     once per P pairs: the P values are added per lane first.
+//   * every thread carries P pairs through the time loop together, so the per-maturity reduction (MaturityTree:
+//     ~3 instructions per maturity, one LDS access per 16 maturities) is paid once per P pairs: the P values are added
+//     per lane first.
 struct ZcbBlockedArgs {
     int64_t n_pairs;
     uint64_t seed, path_offset;
