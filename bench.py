@@ -488,6 +488,7 @@ def main():
         if a.stepper == "superposed":
             # the 20-run validation as ONE launch (hw_zbc_moments_runs): 20 x n pairs in a single grid, no pipelining needed
             # to cover the launch overhead and the drain -- the non-pipelined way to run the reference's 20-run harness
+            respin()                                       # (the reference-stepper kernel ran last)
             ms20 = []
             for _ in range(5):
                 _, ms = e.simulate_ZBC_runs(shard_n, 1234, n_runs=20, seed_stride=12345, return_ms=True)
