@@ -230,6 +230,10 @@ int  hw_comm_create(int32_t n, hw_ctx* const* ctxs, hw_comm** out);
 int  hw_comm_create_ex(int32_t n, hw_ctx* const* ctxs, int32_t flags, hw_comm** out);
 void hw_comm_destroy(hw_comm* comm);
 int  hw_comm_zbc_moments(hw_comm* comm, const hw_zbc_request* req, double out[5], float* wall_ms);
+/* The 20-run validation (hw_zbc_moments_runs) over the fleet: every device prices its shard of the pairs for all n_runs
+ * seeds in ONE launch, then ONE all-reduce of 5*n_runs doubles.  out[n_runs*5], run-major. */
+int  hw_comm_zbc_moments_runs(hw_comm* comm, const hw_zbc_request* req, int32_t n_runs, uint64_t seed_stride, double* out,
+                              float* wall_ms);
 int  hw_comm_zcb_curve(hw_comm* comm, int64_t n_pairs, uint64_t seed, double sigma, double* P_sum, float* wall_ms);
 int  hw_comm_vega_pathwise(hw_comm* comm, int64_t n_paths, uint64_t seed, double S1, double S2, double K,
                            int32_t antithetic, double out[1], float* wall_ms);

@@ -87,6 +87,7 @@ SIGNATURES = {
     "hw_comm_create_ex": (C.c_int, [C.c_int32, C.POINTER(_CTX), C.c_int32, C.POINTER(C.c_void_p)]),
     "hw_comm_destroy": (None, [C.c_void_p]),
     "hw_comm_zbc_moments": (C.c_int, [C.c_void_p, C.POINTER(HwZbcRequest), _DP, C.POINTER(C.c_float)]),
+    "hw_comm_zbc_moments_runs": (C.c_int, [C.c_void_p, C.POINTER(HwZbcRequest), C.c_int32, C.c_uint64, _DP, C.POINTER(C.c_float)]),
     "hw_comm_zcb_curve": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_double, _DP, C.POINTER(C.c_float)]),
     "hw_comm_vega_pathwise": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_double, C.c_double,
                                         C.c_int32, _DP, C.POINTER(C.c_float)]),

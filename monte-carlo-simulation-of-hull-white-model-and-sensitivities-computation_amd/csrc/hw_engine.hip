@@ -753,10 +753,9 @@ int hw_zbc_scenarios(hw_ctx* c, const hw_zbc_request* r, int32_t n_scen, const d
     });
 }
 
-int hw_zbc_moments_runs(hw_ctx* c, const hw_zbc_request* r, int32_t n_runs, uint64_t seed_stride, double* out,
-                        float* kernel_ms)
+// n_runs independent seeds of one request in ONE launch, enqueue only (shared by the single-context and the fleet entry points)
+static int zbc_runs_enqueue(hw_ctx* c, const hw_zbc_request* r, int32_t n_runs, uint64_t seed_stride, double* d_out, hipStream_t st)
 {
-    if (!c || !r || !out) return fail(HW_E_INVALID, "null argument");
     if (n_runs < 1 || 5 * n_runs > kOutCap) return fail(HW_E_INVALID, "n_runs must be 1..%d", kOutCap / 5);
     if (r->stepper != HW_STEPPER_SUPERPOSED) return fail(HW_E_INVALID, "batched runs use the SUPERPOSED stepper");
     int n_steps_S1 = 0;
@@ -765,9 +764,17 @@ int hw_zbc_moments_runs(hw_ctx* c, const hw_zbc_request* r, int32_t n_runs, uint
     Scenario sc;
     rc = build_scenario(c, r->sigma, r->drift_mode, n_steps_S1, r->S1, r->S2, &sc);
     if (rc) return rc;
+    return c->p.precision == HW_F64 ? launch_zbc_superposed<double, 1>(c, r, n_steps_S1, &sc, d_out, st, n_runs, seed_stride)
+                                    : launch_zbc_superposed<float, 1>(c, r, n_steps_S1, &sc, d_out, st, n_runs, seed_stride);
+}
+
+int hw_zbc_moments_runs(hw_ctx* c, const hw_zbc_request* r, int32_t n_runs, uint64_t seed_stride, double* out,
+                        float* kernel_ms)
+{
+    if (!c || !r || !out) return fail(HW_E_INVALID, "null argument");
+    if (n_runs < 1 || 5 * n_runs > kOutCap) return fail(HW_E_INVALID, "n_runs must be 1..%d", kOutCap / 5);
     return timed_sync(c, 5 * n_runs, out, kernel_ms, [&](double* d_out, hipStream_t st) {
-        return c->p.precision == HW_F64 ? launch_zbc_superposed<double, 1>(c, r, n_steps_S1, &sc, d_out, st, n_runs, seed_stride)
-                                        : launch_zbc_superposed<float, 1>(c, r, n_steps_S1, &sc, d_out, st, n_runs, seed_stride);
+        return zbc_runs_enqueue(c, r, n_runs, seed_stride, d_out, st);
     });
 }
 
@@ -1373,6 +1380,18 @@ int hw_comm_zbc_moments(hw_comm* cm, const hw_zbc_request* r, double out[5], flo
         q.n_pairs = cnt;
         q.path_offset = r->path_offset + (uint64_t)off;
         return zbc_enqueue(cm->ctx[g], &q, 1, nullptr, nullptr, d_out, st);
+    });
+}
+
+int hw_comm_zbc_moments_runs(hw_comm* cm, const hw_zbc_request* r, int32_t n_runs, uint64_t seed_stride, double* out, float* wall_ms)
+{
+    if (!cm || !r || !out) return fail(HW_E_INVALID, "null argument");
+    if (n_runs < 1 || 5 * n_runs > kOutCap) return fail(HW_E_INVALID, "n_runs must be 1..%d", kOutCap / 5);
+    return comm_run(cm, r->n_pairs, 5 * n_runs, out, wall_ms, [&](int g, int64_t off, int64_t cnt, double* d_out, hipStream_t st) {
+        hw_zbc_request q = *r;
+        q.n_pairs = cnt;
+        q.path_offset = r->path_offset + (uint64_t)off;
+        return zbc_runs_enqueue(cm->ctx[g], &q, n_runs, seed_stride, d_out, st);
     });
 }
 

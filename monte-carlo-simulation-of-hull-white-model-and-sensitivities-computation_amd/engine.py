@@ -372,6 +372,16 @@ class HullWhiteFleet:
         L.check(self.lib.hw_comm_zbc_moments(self._comm, C.byref(r), _dp(out), C.byref(ms)))
         return (out, ms.value) if return_ms else out
 
+    def simulate_ZBC_runs(self, n_pairs, seed, n_runs=20, seed_stride=12345, path_offset=0, S1=5.0, S2=10.0, K=None,
+                          return_ms=False):
+        """The 20-run validation over the fleet: one launch per device for all runs, one all-reduce of 5*n_runs doubles."""
+        r = self.engines[0]._request(n_pairs, seed, path_offset, S1, S2, K, 0.0, L.HW_DRIFT_BASE, L.HW_STEPPER_SUPERPOSED)
+        out = np.zeros(5 * n_runs, np.float64)
+        ms = C.c_float(0)
+        L.check(self.lib.hw_comm_zbc_moments_runs(self._comm, C.byref(r), int(n_runs), int(seed_stride), _dp(out), C.byref(ms)))
+        out = out.reshape(n_runs, 5)
+        return (out, ms.value) if return_ms else out
+
     def simulate_zcb(self, n_pairs, seed, sigma=0.0):
         out = np.zeros(self.engines[0].params.n_mat, np.float64)
         L.check(self.lib.hw_comm_zcb_curve(self._comm, int(n_pairs), int(seed), float(sigma), _dp(out), None))

@@ -86,14 +86,17 @@ static void validation(app::Fleet& fleet, const app::Options& opt, int64_t n, ui
     const int runs = 20;
     std::vector<double> adj(runs), raw(runs), beta(runs), rho(runs);
     printf("Running %d independent Monte Carlo simulations...\n", runs);
-    // one device: all 20 runs in ONE launch (per-run moment slots); several devices: 20 sharded calls
+    // all 20 runs in ONE launch per device (per-run moment slots; with a communicator: one all-reduce of 100 doubles);
+    // the host-thread fleet and the REFERENCE stepper make 20 sharded calls
     std::vector<double> all(5 * runs, 0.0);
-    const bool batched = fleet.ctx.size() == 1 && opt.stepper == HW_STEPPER_SUPERPOSED;
+    const bool batched = (fleet.ctx.size() == 1 || fleet.comm) && opt.stepper == HW_STEPPER_SUPERPOSED;
     if (batched) {
         const hw_zbc_request r = option_request(opt, n, base_seed);
         float ms = 0.0f;
-        HW_CHECK(hw_zbc_moments_runs(fleet.ctx[0], &r, runs, 12345ull, all.data(), &ms));
-        printf("  (one launch of %d x %lld pairs: %.2f ms, %.2f M paths/sec)\n", runs, (long long)n, ms, (2.0 * n * runs / ms) / 1000.0);
+        if (fleet.comm) HW_CHECK(hw_comm_zbc_moments_runs(fleet.comm, &r, runs, 12345ull, all.data(), &ms));
+        else HW_CHECK(hw_zbc_moments_runs(fleet.ctx[0], &r, runs, 12345ull, all.data(), &ms));
+        printf("  (one launch of %d x %lld pairs%s: %.2f ms, %.2f M paths/sec)\n", runs, (long long)n,
+               fleet.comm ? " per device shard" : "", ms, (2.0 * n * runs / ms) / 1000.0);
     }
     for (int k = 0; k < runs; k++) {
         double* sums = &all[5 * k];

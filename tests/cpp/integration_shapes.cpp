@@ -26,7 +26,10 @@ int main() {
     double sc[10]; hw_zbc_scenarios(ctx, &rq, 2, sig, dm, sc, NULL);
     unsigned long long base = 5; double v20[20]; hw_vega_pathwise_runs(ctx, N_PATHS, base, 0, 5.0, 10.0, K, 0, 20, 982451653ull, v20, &ms);
     hw_ctx* ctxs[1] = {ctx}; hw_comm* comm; hw_comm_create(1, ctxs, &comm); float wall_ms;
-    hw_comm_zbc_moments(comm, &rq, sums, &wall_ms); hw_comm_destroy(comm);
+    hw_comm_zbc_moments(comm, &rq, sums, &wall_ms);
+    hw_comm_zbc_moments_runs(comm, &rq, 20, 12345ull, sums20, &wall_ms);          // the 20-run validation over the fleet
+    hw_comm_destroy(comm);
+    hw_comm_create_ex(1, ctxs, HW_COMM_HOST_SUM, &comm); hw_comm_destroy(comm);   // without RCCL
     hw_destroy(ctx);
     return 0;
 }

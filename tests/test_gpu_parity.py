@@ -442,6 +442,9 @@ def test_comm_threaded_dispatch_rehearsal_with_four_workers(hwmc_mod, oracle_mod
             assert c[0] == 2.0 * 20_000
             np.testing.assert_allclose(c[1:], ref.simulate_zcb(20_000, 5)[1:], rtol=1e-6)   # float row sums regroup with the shards
             assert fleet.simulate_sensitivity(40_000, 9) == pytest.approx(ref.simulate_sensitivity(40_000, 9), rel=1e-13)
+            runs = fleet.simulate_ZBC_runs(30_001, 1234, n_runs=20, seed_stride=12345)   # the 20-run validation over the fleet
+            np.testing.assert_allclose(runs, ref.simulate_ZBC_runs(30_001, 1234, n_runs=20, seed_stride=12345), rtol=1e-13)
+            np.testing.assert_allclose(runs[7], ref.simulate_ZBC_control_variate(30_001, 1234 + 7 * 12345), rtol=1e-13)
             first = fleet.simulate_ZBC_control_variate(4096, 1)
             for i in range(300):                                                       # back to back: workers never sleep
                 assert np.array_equal(fleet.simulate_ZBC_control_variate(4096, 1), first)
