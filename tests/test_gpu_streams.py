@@ -91,7 +91,11 @@ def test_a_destroyed_previous_stream_does_not_poison_the_context(hwmc_mod):
     stream (after synchronising it) before the next call arrives on another stream: the call must go through."""
     import ctypes
     import torch
-    hip = ctypes.CDLL("libamdhip64.so")
+    torch.zeros(1, device="cuda")
+    # the HIP runtime THIS process already runs on (torch's bundled copy or the system's, whichever was loaded first)
+    loaded = [l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l]
+    assert loaded, "no HIP runtime mapped"
+    hip = ctypes.CDLL(loaded[0])
     p = hwmc_mod.default_params("head")
     P, f = hwmc_mod.analytic_curve(p)
     dev = torch.device("cuda", 0)
