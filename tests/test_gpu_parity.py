@@ -409,6 +409,7 @@ def test_comm_one_device_equals_single_context(setup, hwmc_mod):
         c = fleet.simulate_zcb(n, 5)
         assert np.array_equal(c, e.simulate_zcb(n, 5)) and c[0] == 2.0 * n
         assert fleet.simulate_sensitivity(n, 9) == e.simulate_sensitivity(n, 9)
+        assert np.array_equal(fleet.simulate_ZBC_runs(n, 1234, n_runs=20), e.simulate_ZBC_runs(n, 1234, n_runs=20))   # 100 doubles, one all-reduce
         assert np.array_equal(fleet.simulate_ZBC_control_variate(0, 1), np.zeros(5))
     with pytest.raises(hwmc_mod.HwError):
         hwmc_mod.HullWhiteFleet([e, e])                                             # one device twice
