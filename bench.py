@@ -45,11 +45,10 @@ sys.path.insert(0, ROOT)
 #  issue cycles per wave64 instruction per SIMD measured by tools/valu_rates.hip on MI355X: full rate 2, half rate 4,
 #  quarter rate 8).
 VALU_MODEL = {
-    "superposed": {"full": 30, "half": 21, "quarter": 8},   # 14 bitop3,4 xor,4 fmamk,2 mul,4 fma/fmac,2 add | 16 mad_u64,4 cvt,1 pk_fma | 2 log,2 sqrt,2 sin,2 cos
-    # reference stepper, both legs as a 2-vector: per step 2 v_fma (d +- sig_st g), v_pk_fma (r' = r e + t), v_pk_add (r + r'),
-    # v_pk_fma (I += half_dt (r + r')); per block + 4 products for the normals: 14 bitop3,4 xor,4 fmamk,4 mul,8 fma |
-    # 16 mad_u64,4 cvt,8 pk_fma,4 pk_add | 8 transcendentals
-    "reference": {"full": 34, "half": 32, "quarter": 8},
+    "superposed": {"full": 32, "half": 20, "quarter": 8},   # 14 bitop3,4 xor,4 fmamk,2 mul,6 fma/fmac,2 add | 16 mad_u64,4 cvt | 2 log,2 sqrt,2 sin,2 cos
+    # reference stepper: per step and leg v_fma (d +- sig_st g), v_fmac (r' = r e + t), v_add (r + r'), v_fmac (I += half_dt (r + r'));
+    # per block + 4 products for the normals: 14 bitop3,4 xor,4 fmamk,4 mul,8 fma,16 fmac,8 add | 16 mad_u64,4 cvt | 8 transcendentals
+    "reference": {"full": 58, "half": 20, "quarter": 8},
     # double stepper, (y, W) block form: 14 bitop3,4 xor,4 fmamk,3 mul,2 add,2 fma,1 fmac | 16 mad_u64,4 cvt_u32,3 cvt_f64,2 fmac_f64,1 add_f64 | 8 transcendentals
     "superposed_f64": {"full": 30, "half": 26, "quarter": 8},
 }

@@ -119,7 +119,8 @@ int  hw_set_market(hw_ctx* ctx, const float* P, const float* f, int32_t n_mat);
  * automatic choice: 512 when the batch gives every CU >= 4 such workgroups, else 256),
  * grid cap in workgroups per CU (0 = none: one thread slot per pair, the dispatcher hands the workgroups out;
  * with a cap the threads loop), drift-table staging for the REFERENCE stepper (0 scalar loads, 1 LDS), pairs in
- * flight per thread (1 or 2).  Environment, read by hw_create: HWMC_SINGLE_LAUNCH=1 finishes the grid-wide sums
+ * flight per thread (1 or 2; 0 keeps the current choice, -1 returns to automatic: 2 -- their Philox blocks
+ * interleaved -- from four chip-fills of pairs up in the float engine when a path has at most 1024 steps, else 1).  Environment, read by hw_create: HWMC_SINGLE_LAUNCH=1 finishes the grid-wide sums
  * inside the path kernel (sharded tickets) instead of a second launch; HWMC_CURVE_GENERIC=1 always runs the per-step
  * curve kernel.  None of them changes a result beyond the last bits of the double sums. */
 int  hw_set_launch(hw_ctx* ctx, int32_t block_size, int32_t max_blocks_per_cu, int32_t table_in_lds,

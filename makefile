@@ -16,7 +16,7 @@ all: q1 q2 q3
 lib: $(LIB)
 
 $(LIB): $(PKG)/csrc/hw_engine.hip $(PKG)/csrc/hw_kernels.hpp $(PKG)/csrc/hw_model.hpp include/hw_mc.h
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -Wshadow -fPIC -shared $(PKG)/csrc/hw_engine.hip -o $@
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -Wshadow -fno-slp-vectorize -fPIC -shared $(PKG)/csrc/hw_engine.hip -o $@
 
 q1: $(SRC)/1_bond_pricing.cpp $(SRC)/hw_app.hpp $(LIB)
 	@mkdir -p $(BIN) data plots
@@ -46,7 +46,7 @@ run-q3: q3
 # `make microbench` builds the instruction-issue microbenchmarks under tools/
 benchmark: $(SRC)/benchmark_reductions.hip $(LIB)
 	@mkdir -p $(BIN) data plots
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -I include $< -o $(BIN)/$@ $(LDFLAGS)
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I include $< -o $(BIN)/$@ $(LDFLAGS)
 
 run-benchmark: benchmark
 	@mkdir -p data plots
@@ -57,8 +57,8 @@ microbench:
 	$(HIPCC) --offload-arch=gfx950 -O3 tools/valu_rates.hip -o tools/bin/valu_rates
 	$(HIPCC) --offload-arch=gfx950 -O3 tools/valu_patterns.hip -o tools/bin/valu_patterns
 	$(HIPCC) --offload-arch=gfx950 -O3 tools/coissue_probe.hip -o tools/bin/coissue_probe
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -I $(PKG)/csrc tools/loop_lab.hip -o tools/bin/loop_lab
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -I $(PKG)/csrc tools/timeline_probe.hip -o tools/bin/timeline_probe
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I $(PKG)/csrc tools/loop_lab.hip -o tools/bin/loop_lab
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I $(PKG)/csrc tools/timeline_probe.hip -o tools/bin/timeline_probe
 
 run-all: run-q1 run-q2 run-q3
 

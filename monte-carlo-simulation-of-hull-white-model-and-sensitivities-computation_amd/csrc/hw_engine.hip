@@ -88,7 +88,7 @@ struct hw_ctx {
     int block_size = 0;               // 0 = automatic (see geometry())
     int max_blocks_per_cu = 0;        // in units of block_size-thread workgroups; 0 = default
     int table_in_lds = 0;
-    int ilp = 1;
+    int ilp = 0;                      // pairs in flight per thread: 0 = automatic (effective_ilp), 1, 2
     int single_launch = 0;            // 0: path kernel + column pass; 1: in-kernel sharded-ticket finish
     int curve_generic = 0;            // env HWMC_CURVE_GENERIC=1: always run the per-step curve kernel (A/B tests)
     // the last few scenarios built (tables + mean path + A, B cost ~8 us of host time per pricing call otherwise);
@@ -225,6 +225,22 @@ Geometry geometry(const hw_ctx* c, int64_t n_units, int ilp, bool wide_rows = fa
     return g;
 }
 
+// Pairs (paths) in flight per thread of the superposed ZBC / Vega kernels.  Two -- their Philox blocks interleaved
+// (philox_block_prio_x2) -- halve the number of waves and with it the per-wave work outside the time loop (key setup,
+// payoff epilogue, the five DPP reductions in double: ~700 issue cycles a wave).  Measured (tools/ilp_probe.py): +1.0 % at
+// 2^22 pairs and +1.2 % at 2^26 on the 1000-step grid (500 executed steps), nothing below four chip-fills of pairs (the
+// batch then fills the chip only once or twice with half as many waves) and nothing at 2000 executed steps (42.69 vs
+// 42.63 ms at 2^26 pairs: the per-wave overhead is four times smaller there).  So: two from four chip-fills up when the path
+// has at most 1024 steps, in the float (y, W) loop; one for the double engine, the multi-scenario kernel and the per-step
+// fallback under weak mean reversion.  hw_set_launch(pairs_in_flight = 1 | 2) overrides, -1 returns to automatic.
+int effective_ilp(const hw_ctx* c, int64_t n_units, int n_steps, double e, int n_scen)
+{
+    if (c->ilp == 1 || c->ilp == 2) return c->ilp;
+    if (c->p.precision != HW_F32 || n_scen != 1 || n_steps > 1024) return 1;
+    if ((1.0 - (double)(float)e) * std::sqrt((double)n_steps) < 0.05) return 1;       // the guard of ou_walk's (y, W) form
+    return n_units >= (int64_t)4 * 2048 * c->prop.multiProcessorCount ? 2 : 1;
+}
+
 // second launch of the default two-launch finish (no-op when the kernel finished in-launch)
 int finish_columns(hw_ctx* c, hipStream_t st, int rows, int ncol, double* d_out, int n_groups = 1)
 {
@@ -294,7 +310,7 @@ template <typename REAL, int NSCEN>
 int launch_zbc_superposed(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, const Scenario* sc,
                           double* d_out, hipStream_t st, int n_runs = 1, uint64_t seed_stride = 0)
 {
-    const int ilp = c->ilp;
+    const int ilp = effective_ilp(c, r->n_pairs, n_steps_S1, sc[0].k.e, NSCEN);
     const Geometry g = geometry(c, r->n_pairs, ilp);
     if ((int64_t)g.grid * n_runs > ((int64_t)1 << 22)) return fail(HW_E_INVALID, "n_runs x workgroups per run exceeds 2^22");
     const int total_grid = g.grid * n_runs;
@@ -506,7 +522,7 @@ int launch_vega(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset,
         c->vega_key_steps = n_steps_S1;
     }
 
-    const int ilp = c->ilp;
+    const int ilp = effective_ilp(c, n_paths, n_steps_S1, s.k.e, 1);
     const Geometry g = geometry(c, n_paths, ilp);
     if ((int64_t)g.grid * n_runs > ((int64_t)1 << 22)) return fail(HW_E_INVALID, "n_runs x workgroups per run exceeds 2^22");
     const int total_grid = g.grid * n_runs;
@@ -719,10 +735,11 @@ int hw_set_launch(hw_ctx* c, int32_t block_size, int32_t max_blocks_per_cu, int3
         c->block_size = block_size;
     }
     if (max_blocks_per_cu < 0) return fail(HW_E_INVALID, "max_blocks_per_cu < 0");
-    if (pairs_in_flight != 0 && pairs_in_flight != 1 && pairs_in_flight != 2)
-        return fail(HW_E_INVALID, "pairs_in_flight must be 1 or 2");
+    if (pairs_in_flight < -1 || pairs_in_flight > 2)
+        return fail(HW_E_INVALID, "pairs_in_flight must be 1 or 2 (0 keeps the current choice, -1 returns to automatic)");
     c->max_blocks_per_cu = max_blocks_per_cu;
-    if (pairs_in_flight) c->ilp = pairs_in_flight;
+    if (pairs_in_flight > 0) c->ilp = pairs_in_flight;
+    else if (pairs_in_flight == -1) c->ilp = 0;
     c->table_in_lds = table_in_lds ? 1 : 0;
     return HW_OK;
 }
@@ -995,8 +1012,11 @@ int hw_get_launch_geometry(hw_ctx* c, const char* kernel, int64_t n_units, int32
     if (n_units < 0) return fail(HW_E_INVALID, "n_units < 0");
     Geometry g{};
     int64_t row = 0;
-    if (!strcmp(kernel, "zbc") || !strcmp(kernel, "zbc_ref")) { g = geometry(c, n_units, !strcmp(kernel, "zbc") ? c->ilp : 1); row = 5 * 8; }
-    else if (!strcmp(kernel, "vega")) { g = geometry(c, n_units, c->ilp); row = 8; }
+    // (the automatic choice of pairs in flight is evaluated for the reference option: S1 = T_final / 2)
+    const int n_half = std::max(1, hw::steps_to(c->p, c->p.T_final / 2.0));
+    const int ilp_auto = effective_ilp(c, n_units, n_half, hw::step_constants(c->p, c->p.sigma).e, 1);
+    if (!strcmp(kernel, "zbc") || !strcmp(kernel, "zbc_ref")) { g = geometry(c, n_units, !strcmp(kernel, "zbc") ? ilp_auto : 1); row = 5 * 8; }
+    else if (!strcmp(kernel, "vega")) { g = geometry(c, n_units, ilp_auto); row = 8; }
     else if (!strcmp(kernel, "zcb") || !strcmp(kernel, "zcb_blocked")) {
         int P = 1;
         if (!strcmp(kernel, "zcb_blocked")) {

@@ -288,6 +288,84 @@ __device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const Phil
     philox_block_prio<false>(k, pp, 0u, j, o0, o1, o2, o3);
 }
 
+// Block j of TWO paths of one thread in lockstep (pairs in flight = 2): the four multiplies of a round back to back at
+// priority 1, the four key mixes at priority 0 -- two independent dependency chains per wave and half as many priority
+// toggles per pair.  Same words as two philox_block_prio<UHI> calls.  What it buys is half as many waves, i.e. half the
+// per-wave work outside the loop: +1.0 % at 2^22 pairs, +1.2 % at 2^26 with 500 steps per path (tools/ilp_probe.py; see
+// effective_ilp() in hw_engine.hip for when the engine uses it).  Needs -fno-slp-vectorize: left alone, the compiler packs the
+// two pairs' step arithmetic into v_pk_* instructions and pays 12 v_mov per block to build their operands (-5 %).
+template <bool UHI>
+__device__ __forceinline__ void philox_block_prio_x2(const PhiloxKey& k, const PhiloxPath (&pp)[2], const uint32_t (&a2s)[2],
+                                                     uint32_t j, uint32_t (&o)[2][4])
+{
+    uint32_t hi0[2], lo0[2], hi1[2], lo1[2], c0[2], c1[2], c2[2], c3[2];
+    uint32_t rh, rl;
+    mulhilo(kM0, j, rh, rl);                        // round 1 (scalar, shared by both paths)
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        if constexpr (UHI) {
+            uint32_t shi, slo;
+            mulhilo(kM1, a2s[q] ^ rh, shi, slo);    // round 2, word-2 product (scalar)
+            c0[q] = shi ^ pp[q].Q;
+            c2[q] = pp[q].R ^ rl;
+            mulhilo(kM0, c0[q], hi0[q], lo0[q]);    // round 3
+            mulhilo(kM1, c2[q], hi1[q], lo1[q]);
+            c1[q] = slo ^ k.s_k0_2;                 // (scalar) folded into the first key mix below
+        } else {
+            c2[q] = pp[q].A2 ^ rh;
+            c3[q] = rl;
+            mulhilo(kM1, c2[q], hi1[q], lo1[q]);    // round 2
+            c0[q] = hi1[q] ^ pp[q].Q;
+            c1[q] = lo1[q];
+            c2[q] = pp[q].R ^ c3[q];
+            mulhilo(kM0, c0[q], hi0[q], lo0[q]);    // round 3
+            mulhilo(kM1, c2[q], hi1[q], lo1[q]);
+        }
+    }
+    pin4(hi0[0], hi1[0], hi0[1], hi1[1]);
+    HWK_SETPRIO(0);
+    pin4(hi0[0], hi1[0], hi0[1], hi1[1]);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        if constexpr (UHI) c0[q] = hi1[q] ^ c1[q];
+        else c0[q] = xor3(hi1[q], c1[q], k.k0[2]);
+        c1[q] = lo1[q];
+        c2[q] = hi0[q] ^ pp[q].T;
+        c3[q] = lo0[q];
+    }
+#pragma unroll
+    for (int r = 3; r < 10; r++) {                  // rounds 4..10
+        pin4(c0[0], c2[0], c0[1], c2[1]);
+        HWK_SETPRIO_R(1);
+        pin4(c0[0], c2[0], c0[1], c2[1]);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            mulhilo(kM0, c0[q], hi0[q], lo0[q]);
+            mulhilo(kM1, c2[q], hi1[q], lo1[q]);
+        }
+        pin4(hi0[0], hi1[0], hi0[1], hi1[1]);
+        HWK_SETPRIO_R(0);
+        pin4(hi0[0], hi1[0], hi0[1], hi1[1]);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            c0[q] = xor3(hi1[q], c1[q], k.k0[r]);
+            c1[q] = lo1[q];
+            c2[q] = xor3(hi0[q], c3[q], k.k1[r]);
+            c3[q] = lo0[q];
+        }
+    }
+    pin4(c0[0], c1[0], c2[0], c3[0]);
+    pin4(c0[1], c1[1], c2[1], c3[1]);
+    HWK_SETPRIO(1);
+    pin4(c0[0], c1[0], c2[0], c3[0]);
+    pin4(c0[1], c1[1], c2[1], c3[1]);
+#pragma unroll
+    for (int q = 0; q < 2; q++) { o[q][0] = c0[q]; o[q][1] = c1[q]; o[q][2] = c2[q]; o[q][3] = c3[q]; }
+}
+#ifndef HWK_ILP2_INTERLEAVE
+#define HWK_ILP2_INTERLEAVE 1     // 0: two pairs in flight run their blocks one after the other (round 1's form: never faster)
+#endif
+
 // Is the high word of the path id the same in all lanes?  Returns it (xor k1[0]) in an SGPR.
 __device__ __forceinline__ bool philox_uniform_hi(const PhiloxPath& pp, uint32_t& a2s)
 {
@@ -786,6 +864,24 @@ __device__ __forceinline__ void ou_walk(const PhiloxKey& key, const PhiloxPath (
             constexpr bool UHI = decltype(tag)::value;
             constexpr int BASE = decltype(base_tag)::value;
             for (int j = j0; j < j1; j++) {
+#if HWK_ILP2_INTERLEAVE
+                if constexpr (ILP == 2) {
+                    uint32_t w[2][4];
+                    philox_block_prio_x2<UHI>(key, pp, a2s, (uint32_t)j, w);
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        float s0, sn0, cs0, s1, sn1, cs1;
+                        box_muller_parts(w[q][0], w[q][1], s0, sn0, cs0);
+                        box_muller_parts(w[q][2], w[q][3], s1, sn1, cs1);
+                        const float a0 = __builtin_fmaf(e, sn0, cs0), a1 = __builtin_fmaf(e, sn1, cs1);
+                        const float b0 = sn0 + cs0, b1 = sn1 + cs1;
+                        const float t = __builtin_fmaf(e2, y[q], s0 * a0);
+                        y[q] = __builtin_fmaf(e2, t, s1 * a1);
+                        W[q] = __builtin_fmaf(s1, b1, __builtin_fmaf(s0, b0, W[q]));
+                    }
+                    continue;
+                }
+#endif
 #pragma unroll
                 for (int q = 0; q < ILP; q++) {
                     uint32_t w0, w1, w2, w3;

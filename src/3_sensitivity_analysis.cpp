@@ -54,7 +54,7 @@ static void block_size_sweep(app::Fleet& fleet, int64_t n, uint64_t seed)
     const double K = (double)expf(-0.1f);
     for (int i = 0; i < n_sizes; i++) {
         const int bs = sizes[i];
-        HW_CHECK(hw_set_launch(fleet.ctx[0], bs, 0, 0, 1));
+        HW_CHECK(hw_set_launch(fleet.ctx[0], bs, 0, 0, 0));
         double out;
         float ms = 0.0f, total = 0.0f;
         HW_CHECK(hw_vega_pathwise(fleet.ctx[0], n, seed, 0, kS1, kS2, K, 0, &out, &ms));          // warm-up, 3_sens:307-310
@@ -74,7 +74,7 @@ static void block_size_sweep(app::Fleet& fleet, int64_t n, uint64_t seed)
         printf("  %4d threads/block: %5.1f%%%s%s\n", sizes[i], rel, sizes[i] == best ? " OPTIMAL" : "",
                rel < 90.0f ? " too small, high overhead" : "");
     }
-    HW_CHECK(hw_set_launch(fleet.ctx[0], -1, 0, 0, 1));                                           // back to the automatic choice
+    HW_CHECK(hw_set_launch(fleet.ctx[0], -1, 0, 0, -1));                                          // back to the automatic choice
 }
 
 int main(int argc, char** argv)

@@ -44,7 +44,7 @@ def test_defaults_follow_the_driver_contract(bench, monkeypatch):
     assert a.gpus == 1 and a.steps == 20 and a.warmup == 3                 # no flags: N = 1, finishes within minutes
     assert a.scaling == "strong" and a.total_log2 == 24 and a.allreduce_every == 1 and a.paths_log2 == 20
     # the VALU model bench.py prices the loop with is the one the census test pins
-    assert bench.VALU_MODEL["superposed"] == {"full": 30, "half": 21, "quarter": 8}
+    assert bench.VALU_MODEL["superposed"] == {"full": 32, "half": 20, "quarter": 8}
     assert bench.VALU_MODEL["superposed_f64"] == {"full": 30, "half": 26, "quarter": 8}
 
 

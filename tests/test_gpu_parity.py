@@ -134,7 +134,44 @@ def test_zbc_lds_table_variant_and_launch_knobs(setup, hwmc_mod):
             np.testing.assert_allclose(e.simulate_zcb(700, 5), o.zcb_curve(700, 5), rtol=REL_F32)
             assert e.simulate_sensitivity(n, 9) == pytest.approx(o.vega_pathwise(P, f, n, 9), rel=REL_F32)
     finally:
-        e.set_launch(-1, 0, 0, 1)
+        e.set_launch(-1, 0, 0, -1)
+
+
+def test_two_pairs_in_flight_interleaved_blocks(setup, hwmc_mod):
+    """pairs_in_flight = 2 (the engine's automatic choice from four chip-fills of pairs up): the Philox blocks of a
+    thread's two pairs run in lockstep (philox_block_prio_x2).  Per pair the arithmetic is the one-pair loop's, so the
+    sums must equal the one-pair launch to 1e-13 (only the grouping of the double additions differs) and the oracle to
+    1e-5 -- ragged counts, ids straddling a multiple of 2^32 (the per-lane round-2 multiply), 1..3 tail steps, the Vega
+    kernel, batched runs, and the automatic switch at 2^22 pairs."""
+    e, o, P, f = setup("head")
+    try:
+        for n, off in ((5000, 0), (70_001, 123), (4097, (1 << 32) - 2000), (300, (5 << 32) - 150)):
+            want = o.zbc_moments(P, f, n, 77, path_offset=off)
+            e.set_launch(pairs_in_flight=1)
+            one = e.simulate_ZBC_control_variate(n, 77, path_offset=off)
+            e.set_launch(pairs_in_flight=2)
+            two = e.simulate_ZBC_control_variate(n, 77, path_offset=off)
+            np.testing.assert_allclose(two, one, rtol=1e-13, err_msg="n=%d off=%d" % (n, off))
+            np.testing.assert_allclose(two, want, rtol=REL_F32)
+            v1 = e.simulate_sensitivity(n, 9, path_offset=off)
+            e.set_launch(pairs_in_flight=1)
+            assert e.simulate_sensitivity(n, 9, path_offset=off) == pytest.approx(v1, rel=1e-12)
+            e.set_launch(pairs_in_flight=2)
+        np.testing.assert_allclose(e.simulate_ZBC_control_variate(3000, 5, S1=4.97), o.zbc_moments(P, f, 3000, 5, S1=4.97), rtol=REL_F32)   # 497 steps: tail of 1
+        runs = e.simulate_ZBC_runs(6000, 1234, n_runs=3)
+        for k in range(3):
+            assert np.array_equal(runs[k], e.simulate_ZBC_control_variate(6000, 1234 + k * 12345))
+        # automatic: one pair below four chip-fills, two from there on -- same sums either way
+        e.set_launch(pairs_in_flight=-1)
+        cus = e.device_info()["compute_units"]
+        n_big = 4 * 2048 * cus + 333
+        assert e.launch_geometry("zbc", n_big)["grid"] * 2 * 512 >= n_big > e.launch_geometry("zbc", n_big)["grid"] * 512
+        assert e.launch_geometry("zbc", n_big - 1000)["grid"] * 512 >= n_big - 1000
+        auto = e.simulate_ZBC_control_variate(n_big, 3)
+        e.set_launch(pairs_in_flight=1)
+        np.testing.assert_allclose(auto, e.simulate_ZBC_control_variate(n_big, 3), rtol=1e-13)
+    finally:
+        e.set_launch(-1, 0, 0, -1)
 
 
 def test_zbc_edge_cases_and_sharding(setup, hwmc_mod):

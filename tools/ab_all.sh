@@ -1,0 +1,9 @@
+#!/bin/bash
+# A/B of ALL path kernels for several engine builds on one box: tools/ab_all.sh ROUNDS lib1.so lib2.so ...
+R=$1; shift
+for ((i = 0; i < R; i++)); do
+  for L in "$@"; do
+    echo "== $(basename $L)"
+    HWMC_LIB=$L python tools/time_kernels.py 2>/dev/null | grep -v "^kernel"
+  done
+done

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Instruction census of the hot loop of a kernel in a gfx950 assembly listing.
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S -o eng.s <package>/csrc/hw_engine.hip
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize --cuda-device-only -S -o eng.s <package>/csrc/hw_engine.hip
     python tools/loop_census.py eng.s zbc_superposed_kernelIfLi1ELi1E
 Finds the kernel whose mangled name contains the pattern, takes its innermost loops with at least 10 wide multiplies and counts
 opcodes (the numbers quoted in DESIGN.md section 5 and in bench.py's VALU_MODEL come from here)."""
