@@ -1316,6 +1316,21 @@ static int comm_run(hw_comm* cm, int64_t n_units, int count_out, double* out, fl
     return rc;
 }
 
+// A request one device would refuse must be refused HERE, on the calling thread, for all of them: a worker that
+// returns before it has enqueued its all-reduce leaves the other ranks waiting in theirs for ever.
+static int comm_check(hw_comm* cm, const hw_zbc_request* r)
+{
+    for (hw_ctx* c : cm->ctx) {
+        int n_steps_S1 = 0;
+        const int rc = check_request(c, r, &n_steps_S1);
+        if (rc) return rc;
+        if (r->stepper == HW_STEPPER_REFERENCE && c->p.precision != HW_F32) return fail(HW_E_INVALID, "the REFERENCE stepper is float32 only");
+        if (r->stepper != HW_STEPPER_REFERENCE && r->stepper != HW_STEPPER_SUPERPOSED) return fail(HW_E_INVALID, "unknown stepper %d", r->stepper);
+        if (r->drift_mode != HW_DRIFT_BASE && r->drift_mode != HW_DRIFT_SHIFTED) return fail(HW_E_INVALID, "drift_mode must be HW_DRIFT_BASE or HW_DRIFT_SHIFTED");
+    }
+    return HW_OK;
+}
+
 extern "C" {
 
 int hw_comm_create(int32_t n, hw_ctx* const* ctxs, hw_comm** out) { return hw_comm_create_ex(n, ctxs, HW_COMM_RCCL, out); }
@@ -1395,6 +1410,7 @@ void hw_comm_destroy(hw_comm* cm)
 int hw_comm_zbc_moments(hw_comm* cm, const hw_zbc_request* r, double out[5], float* wall_ms)
 {
     if (!cm || !r || !out) return fail(HW_E_INVALID, "null argument");
+    if (const int rcq = comm_check(cm, r)) return rcq;
     return comm_run(cm, r->n_pairs, 5, out, wall_ms, [&](int g, int64_t off, int64_t cnt, double* d_out, hipStream_t st) {
         hw_zbc_request q = *r;
         q.n_pairs = cnt;
@@ -1407,6 +1423,7 @@ int hw_comm_zbc_moments_runs(hw_comm* cm, const hw_zbc_request* r, int32_t n_run
 {
     if (!cm || !r || !out) return fail(HW_E_INVALID, "null argument");
     if (n_runs < 1 || 5 * n_runs > kOutCap) return fail(HW_E_INVALID, "n_runs must be 1..%d", kOutCap / 5);
+    if (const int rcq = comm_check(cm, r)) return rcq;
     return comm_run(cm, r->n_pairs, 5 * n_runs, out, wall_ms, [&](int g, int64_t off, int64_t cnt, double* d_out, hipStream_t st) {
         hw_zbc_request q = *r;
         q.n_pairs = cnt;
@@ -1418,7 +1435,10 @@ int hw_comm_zbc_moments_runs(hw_comm* cm, const hw_zbc_request* r, int32_t n_run
 int hw_comm_zcb_curve(hw_comm* cm, int64_t n_pairs, uint64_t seed, double sigma, double* P_sum, float* wall_ms)
 {
     if (!cm || !P_sum) return fail(HW_E_INVALID, "null argument");
+    if (n_pairs < 0) return fail(HW_E_INVALID, "n_pairs < 0");
     const int n_mat = cm->ctx[0]->p.n_mat;
+    for (hw_ctx* c : cm->ctx)
+        if (c->p.n_mat != n_mat) return fail(HW_E_INVALID, "the contexts of a communicator must share n_mat");
     int rc = comm_run(cm, n_pairs, n_mat, P_sum, wall_ms, [&](int g, int64_t off, int64_t cnt, double* d_out, hipStream_t st) {
         return zcb_enqueue(cm->ctx[g], cnt, seed, (uint64_t)off, sigma, d_out, st);
     });
@@ -1429,6 +1449,11 @@ int hw_comm_vega_pathwise(hw_comm* cm, int64_t n_paths, uint64_t seed, double S1
                           int32_t antithetic, double out[1], float* wall_ms)
 {
     if (!cm || !out) return fail(HW_E_INVALID, "null argument");
+    {
+        hw_zbc_request q{};
+        q.n_pairs = n_paths; q.S1 = S1; q.S2 = S2; q.K = K;
+        if (const int rcq = comm_check(cm, &q)) return rcq;
+    }
     return comm_run(cm, n_paths, 1, out, wall_ms, [&](int g, int64_t off, int64_t cnt, double* d_out, hipStream_t st) {
         return vega_enqueue(cm->ctx[g], cnt, seed, (uint64_t)off, S1, S2, K, antithetic, d_out, st);
     });

@@ -489,9 +489,12 @@ def test_comm_threaded_dispatch_rehearsal_with_four_workers(hwmc_mod, oracle_mod
             for pause in (0.002, 0.05, 0.3):                                           # longer than the 100 us spin: futex path
                 time.sleep(pause)
                 assert np.array_equal(fleet.simulate_ZBC_control_variate(4096, 1), first)
-            with pytest.raises(hwmc_mod.HwError) as ei:                                # S2 > T_final: rejected on the worker threads
-                fleet.simulate_ZBC_control_variate(4096, 1, S1=5.0, S2=11.0)
-            assert "device" in str(ei.value) and "S1 < S2" in str(ei.value)
+            with pytest.raises(hwmc_mod.HwError) as ei:                                # S2 > T_final: refused on the calling thread,
+                fleet.simulate_ZBC_control_variate(4096, 1, S1=5.0, S2=11.0)           # before any worker could sit in an all-reduce
+            assert "S1 < S2" in str(ei.value) and "device" not in str(ei.value)
+            with pytest.raises(hwmc_mod.HwError) as ei:                                # found by the workers only (launch geometry):
+                fleet.simulate_ZBC_runs(1 << 27, 1, n_runs=200, seed_stride=1)         # nothing is launched, the text travels back
+            assert "device 0" in str(ei.value) and "2^22" in str(ei.value)
             assert np.array_equal(fleet.simulate_ZBC_control_variate(4096, 1), first)   # and the communicator still works
         with pytest.raises(hwmc_mod.HwError):
             hwmc_mod.HullWhiteFleet([engines[0], engines[0]], host_sum=True)           # the same context twice
