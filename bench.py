@@ -468,6 +468,21 @@ def main():
         per_rank_kernel_ms = [float(x.item()) for x in allk]
 
     extras = {}
+    if world == 1 and not a.no_extras and S > 1:
+        # The same alternation over 10 K steps in ONE region: what the two edges of a K-step region cost.  After a
+        # synchronisation both queues start together and the launches need ~10 steps to settle into the staggered rhythm in
+        # which one launch's drain is filled by the other queue (tools/region_edge_probe.py: T = ~60 us + K x steady).
+        respin()
+        k_long = 10 * K
+        torch.cuda.synchronize()
+        tl = time.perf_counter()
+        for i in range(k_long):
+            enqueue(i, 1234 + 12345 * i, scratch[i % K])
+        torch.cuda.synchronize()
+        long_ms = (time.perf_counter() - tl) * 1e3 / k_long
+        extras["long_region"] = {"steps": k_long, "ms_per_step": long_ms, "value": (2 * shard_n / long_ms) / 1000.0, "unit": "M paths/s",
+                                 "note": "untimed side measurement: 10 K steps between two synchronisations instead of K; the difference to "
+                                         "`value` is the cost of starting and draining the two-queue pipeline once per K steps"}
     if world == 1 and not a.no_extras:
         # the OTHER stepper on the same workload: the reference's per-step arithmetic verbatim vs the superposed recursion
         other = hwmc.HW_STEPPER_REFERENCE if a.stepper == "superposed" else hwmc.HW_STEPPER_SUPERPOSED

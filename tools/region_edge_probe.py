@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""What do the two EDGES of a timed region cost?  bench.py times K = 20 pricing calls between synchronisations; 200 calls
+in one go run at a lower time per call (tools/priority_probe.py).  This probe separates the candidates:
+  (1) T(K) for K = 5 ... 400 after a plain synchronise: the fit T = edge + K * steady gives the cost of the edges;
+  (2) K = 20 after an idle gap of 0 / 50 us / 200 us / 1 ms / 5 ms / 20 ms (host sleep after the synchronise): does the
+      chip lose its clock while it waits for the host?
+  (3) K = 20 timed by the host with torch.cuda.synchronize() against polling the closing event first.
+All with two contexts/streams alternating, 2^20 pairs per call, host wall clock and a HIP event pair per region.
+    python tools/region_edge_probe.py [log2 pairs = 20]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import hwmc  # noqa: E402
+
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 20)
+p = hwmc.default_params("head")
+P, f = hwmc.analytic_curve(p)
+engines = []
+for _ in range(2):
+    e = hwmc.HullWhiteEngine(p, device=0)
+    e.load_market_data(P, f)
+    engines.append(e)
+out = torch.zeros((512, 5), dtype=torch.float64, device=dev)
+cands = [torch.cuda.Stream(device=dev) for _ in range(8)]
+streams = cands[:2]
+
+
+def region(K, gap_s=0.0, poll=False, n_streams=2):
+    torch.cuda.synchronize()
+    if gap_s > 0:
+        t_end = time.perf_counter() + gap_s
+        while time.perf_counter() < t_end:
+            pass
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(streams[0])
+    for i in range(K):
+        k = i % n_streams
+        engines[k].enqueue_ZBC(out[i % 512].data_ptr(), n, 1234 + i, stream=streams[k].cuda_stream)
+    if n_streams > 1:
+        streams[0].wait_stream(streams[1])
+    ev1.record(streams[0])
+    t_enq = time.perf_counter()
+    if poll:
+        while not ev1.query():
+            pass
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    return (t1 - t0) * 1e3, ev0.elapsed_time(ev1), (t_enq - t0) * 1e3
+
+
+def warm(ms=300.0):
+    t_end = time.perf_counter() + ms * 1e-3
+    while time.perf_counter() < t_end:
+        region(40)
+
+
+def med(K, reps=9, **kw):
+    warm(60.0)
+    rows = np.array([region(K, **kw) for _ in range(reps)])
+    return np.median(rows, axis=0)
+
+
+warm()
+# which two of the candidate streams overlap (do not share a hardware queue) is a lottery: take the best pair, as bench.py does
+best = (1e9, None)
+for i in range(8):
+    for j in range(i + 1, 8):
+        streams = [cands[i], cands[j]]
+        t = min(region(16)[0] for _ in range(2)) / 16
+        if t < best[0]:
+            best = (t, (i, j))
+streams = [cands[best[1][0]], cands[best[1][1]]]
+print("stream pair %s: %.4f ms per call over 16 calls" % (best[1], best[0]))
+warm()
+print("(1) region length: host ms, event ms, host time to enqueue; per call")
+Ks = [5, 10, 20, 40, 80, 200, 400]
+host, evt = [], []
+for K in Ks:
+    h, e_, q = med(K)
+    host.append(h)
+    evt.append(e_)
+    print("  K = %3d   host %8.4f ms  (%.4f per call)   events %8.4f ms  (%.4f per call)   enqueue %.3f ms" % (K, h, h / K, e_, e_ / K, q), flush=True)
+A = np.vstack([np.ones(len(Ks)), Ks]).T
+(edge_h, steady_h), *_ = np.linalg.lstsq(A, np.array(host), rcond=None)
+(edge_e, steady_e), *_ = np.linalg.lstsq(A, np.array(evt), rcond=None)
+print("  fit host  : T = %.1f us + K * %.2f us   -> %.0f M paths/s steady" % (edge_h * 1e3, steady_h * 1e3, 2 * n / steady_h / 1e3))
+print("  fit events: T = %.1f us + K * %.2f us" % (edge_e * 1e3, steady_e * 1e3))
+h1, e1, _ = med(20, n_streams=1)
+print("  one stream, K = 20: host %.4f per call, events %.4f per call" % (h1 / 20, e1 / 20))
+
+print("(2) K = 20 after an idle gap")
+for gap in (0.0, 50e-6, 200e-6, 1e-3, 5e-3, 20e-3):
+    h, e_, _ = med(20, gap_s=gap)
+    print("  gap %7.0f us   host %.4f per call   events %.4f per call   (%.0f M paths/s)" % (gap * 1e6, h / 20, e_ / 20, 2 * n * 20 / h / 1e3), flush=True)
+
+print("(3) how the host waits, K = 20")
+for poll in (False, True):
+    h, e_, _ = med(20, poll=poll, reps=15)
+    print("  %-44s host %.4f per call   events %.4f per call" % ("poll the closing event, then synchronize" if poll else "torch.cuda.synchronize()", h / 20, e_ / 20))
