@@ -62,17 +62,10 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
     return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
 }
 
-// Round keys 3..10 are consumed by every block of the loop.  HWK_KEYS_IN_VGPRS=1 copies them to vector
-// registers once per thread (an SGPR operand on back-to-back v_bitop3 costs 4.1 cycles instead of 2.45).
-#ifndef HWK_CVT_AT_PRIO0
-#define HWK_CVT_AT_PRIO0 0
-#endif
-#ifndef HWK_KEYS_IN_VGPRS
-#define HWK_KEYS_IN_VGPRS 1
-#endif
+// Round keys 3..10 are consumed by every block of the loop: they are copied to vector registers once per
+// thread (an SGPR operand on back-to-back v_bitop3 costs 4.1 cycles instead of 2.45).
 __device__ __forceinline__ void philox_key_to_vgprs(PhiloxKey& k)
 {
-#if HWK_KEYS_IN_VGPRS
 #pragma unroll
     for (int r = 2; r < 10; r++) {
         uint32_t a, b;
@@ -81,9 +74,6 @@ __device__ __forceinline__ void philox_key_to_vgprs(PhiloxKey& k)
         k.k0[r] = a;
         k.k1[r] = b;
     }
-#else
-    (void)k;
-#endif
 }
 
 __device__ __forceinline__ void mulhilo(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo)
@@ -198,18 +188,9 @@ __device__ __forceinline__ void normal4(const PhiloxKey& k, const PhiloxPath& pp
         __builtin_amdgcn_sched_barrier(0);    \
     } while (0)
 
-// the toggles INSIDE the Philox rounds (experiments: -DHWK_PRIO_ROUNDS=0 keeps only the block-level phases,
-// -DHWK_PRIO_ROUNDS=2 uses priorities 0/2/3 instead of 0/1)
-#ifndef HWK_PRIO_ROUNDS
-#define HWK_PRIO_ROUNDS 1
-#endif
-#if HWK_PRIO_ROUNDS == 1
+// the toggles INSIDE the Philox rounds (block-level phases only, or priorities 0/2/3 instead of 0/1, measured slower:
+// DESIGN.md section 5)
 #define HWK_SETPRIO_R(n) HWK_SETPRIO(n)
-#elif HWK_PRIO_ROUNDS == 2
-#define HWK_SETPRIO_R(n) HWK_SETPRIO(((n) & 1) ? 2 : 0)
-#else
-#define HWK_SETPRIO_R(n) do { } while (0)
-#endif
 
 __device__ __forceinline__ void pin2(uint32_t& a, uint32_t& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void pin4(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d)
@@ -806,17 +787,9 @@ __global__ void finalize_columns_kernel(const double* __restrict__ partials, int
 // block on y instead of four.  1 - e is exact in float (Sterbenz), and the rounding of W - e y, divided by
 // 1 - e ~ 1e-2..2.5e-3, stays at ~2e-6 of S: the same size as the rounding of 500..2000 sequential adds.
 // (Guard and measurements for weaker mean reversion: see the comment in ou_walk.)
-// The HWK_* macros below switch on experiments that were measured and NOT adopted.
+// Experiments that were measured and NOT adopted are listed in DESIGN.md section 5; the A/B switches that remain
+// (HWK_F64_BLOCK_FORM, HWK_ILP2_INTERLEAVE, HWK_MATURITY_TREE) select between two forms that are both tested.
 // ------------------------------------------------------------------------------------------
-#ifndef HWK_PROGRESS_PRIO
-#define HWK_PROGRESS_PRIO 0
-#endif
-#ifndef HWK_STEPS_PRIO0
-#define HWK_STEPS_PRIO0 0
-#endif
-#ifndef HWK_ANGLE_BITS
-#define HWK_ANGLE_BITS 0
-#endif
 #ifndef HWK_F64_BLOCK_FORM
 #define HWK_F64_BLOCK_FORM 1     // 0: the double stepper runs one fma + one add per step on converted normals (A/B)
 #endif
@@ -824,13 +797,7 @@ __device__ __forceinline__ void box_muller_parts(uint32_t x, uint32_t y, float& 
 {
     constexpr float kInv = 2.3283064e-10f;
     const float u = __builtin_fmaf((float)x, kInv, kInv);
-#if HWK_ANGLE_BITS
-    // experiment: the angle in revolutions as 1 + (top 23 bits of y) 2^-23 in [1, 2), one v_alignbit_b32 instead of
-    // v_cvt_f32_u32 + v_fmamk_f32; v_sin/v_cos are periodic in whole revolutions
-    const float w = __builtin_bit_cast(float, __builtin_amdgcn_alignbit(0x7Fu, y, 9u));
-#else
     const float w = __builtin_fmaf((float)y, kInv, kInv);
-#endif
     s = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u));
     sn = __builtin_amdgcn_sinf(w);
     cs = __builtin_amdgcn_cosf(w);
@@ -886,55 +853,19 @@ __device__ __forceinline__ void ou_walk(const PhiloxKey& key, const PhiloxPath (
                 for (int q = 0; q < ILP; q++) {
                     uint32_t w0, w1, w2, w3;
                     float s0, sn0, cs0, s1, sn1, cs1;
-#if HWK_CVT_AT_PRIO0
-                    philox_block_prio<UHI, false, BASE>(key, pp[q], a2s[q], (uint32_t)j, w0, w1, w2, w3);
-                    constexpr float kInv = 2.3283064e-10f;
-                    float u0 = __builtin_fmaf((float)w0, kInv, kInv), v0 = __builtin_fmaf((float)w1, kInv, kInv);
-                    float u1 = __builtin_fmaf((float)w2, kInv, kInv), v1 = __builtin_fmaf((float)w3, kInv, kInv);
-                    asm volatile("" : "+v"(u0), "+v"(v0), "+v"(u1), "+v"(v1));
-                    HWK_SETPRIO(1);
-                    asm volatile("" : "+v"(u0), "+v"(v0), "+v"(u1), "+v"(v1));
-                    s0 = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u0));
-                    sn0 = __builtin_amdgcn_sinf(v0);
-                    cs0 = __builtin_amdgcn_cosf(v0);
-                    s1 = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u1));
-                    sn1 = __builtin_amdgcn_sinf(v1);
-                    cs1 = __builtin_amdgcn_cosf(v1);
-#else
                     philox_block_prio<UHI, true, BASE>(key, pp[q], a2s[q], (uint32_t)j, w0, w1, w2, w3);
                     box_muller_parts(w0, w1, s0, sn0, cs0);
                     box_muller_parts(w2, w3, s1, sn1, cs1);
-#endif
-#if HWK_STEPS_PRIO0
-                    asm volatile("" : "+v"(s0), "+v"(sn0), "+v"(cs0), "+v"(s1), "+v"(sn1), "+v"(cs1));
-                    HWK_SETPRIO(0);
-                    asm volatile("" : "+v"(s0), "+v"(sn0), "+v"(cs0), "+v"(s1), "+v"(sn1), "+v"(cs1));
-#endif
                     const float a0 = __builtin_fmaf(e, sn0, cs0), a1 = __builtin_fmaf(e, sn1, cs1);
                     const float b0 = sn0 + cs0, b1 = sn1 + cs1;
                     const float t = __builtin_fmaf(e2, y[q], s0 * a0);
                     y[q] = __builtin_fmaf(e2, t, s1 * a1);
                     W[q] = __builtin_fmaf(s1, b1, __builtin_fmaf(s0, b0, W[q]));
-#if HWK_STEPS_PRIO0
-                    asm volatile("" : "+v"(y[q]), "+v"(W[q]));
-                    HWK_SETPRIO(1);
-                    asm volatile("" : "+v"(y[q]), "+v"(W[q]));
-#endif
                 }
             }
         };
         auto blocks = [&](auto tag) {
-#if HWK_PROGRESS_PRIO
-            // experiment: the first half of a wave's life at priorities 2/3, the second at 0/1, so that waves
-            // that are behind overtake the ones ahead (the arbiter otherwise favours the oldest wave)
-            const int mid = nblk >> 1;
-            __builtin_amdgcn_s_setprio(3);
-            blocks_range(tag, std::integral_constant<int, 2>{}, 0, mid);
-            __builtin_amdgcn_s_setprio(1);
-            blocks_range(tag, std::integral_constant<int, 0>{}, mid, nblk);
-#else
             blocks_range(tag, std::integral_constant<int, 0>{}, 0, nblk);
-#endif
         };
         if (uhi) blocks(std::true_type{});
         else blocks(std::false_type{});
@@ -1172,18 +1103,7 @@ zbc_reference_kernel(const ZbcRefArgs a, const float* __restrict__ drift, double
     // scalar operand; with sig_st scalar too, every step paid a v_mov to bring d into a vector register
     float sig_v;
     asm volatile("v_mov_b32 %0, %1" : "=v"(sig_v) : "s"(a.sig_st));
-#ifndef HWK_REF_STEPS_PRIO0
-#define HWK_REF_STEPS_PRIO0 0
-#endif
-#ifndef HWK_REF_E_VGPR
-#define HWK_REF_E_VGPR 0        // A/B: no gain
-#endif
-#if HWK_REF_E_VGPR
-    float e_v;                                           // likewise e: the packed r' = r e + t takes {e, e} from registers
-    asm volatile("v_mov_b32 %0, %1" : "=v"(e_v) : "s"(a.e));
-#else
     const float e_v = a.e;
-#endif
 
     double acc[5] = {0, 0, 0, 0, 0};
     for (int it = 0; it < a.iters; it++) {
@@ -1211,20 +1131,10 @@ zbc_reference_kernel(const ZbcRefArgs a, const float* __restrict__ drift, double
                 float g[4];                                          // the four drifts come with ONE wave-uniform load
                 normal4_prio<UHI>(vkey, pp, a2s, (uint32_t)(i >> 2), g);
                 const float d0 = tab[i], d1 = tab[i + 1], d2 = tab[i + 2], d3 = tab[i + 3];
-#if HWK_REF_STEPS_PRIO0
-                asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]));
-                HWK_SETPRIO(0);
-                asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]));
-#endif
                 step(d0, g[0]);
                 step(d1, g[1]);
                 step(d2, g[2]);
                 step(d3, g[3]);
-#if HWK_REF_STEPS_PRIO0
-                asm volatile("" : "+v"(r1), "+v"(r2), "+v"(I1), "+v"(I2));
-                HWK_SETPRIO(1);
-                asm volatile("" : "+v"(r1), "+v"(r2), "+v"(I1), "+v"(I2));
-#endif
             }
             if (nfull < a.n_steps) {                                 // 1..3 remaining steps
                 float g[4];
@@ -1372,37 +1282,10 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
     const int nblk = a.n_steps >> 2, half_stride = a.stride >> 1;
     // e^2 multiplies y twice per block next to a VGPR partner (v_pk_fma_f32 {e2, s1} x {y, b1}): held in a vector
     // register it needs no v_mov per block to build that pair
-#ifndef HWK_CURVE_E2_VGPR
-#define HWK_CURVE_E2_VGPR 1
-#endif
-#ifndef HWK_CURVE_SKIP_LIVE
-#define HWK_CURVE_SKIP_LIVE 0     // 1: a copy of the time loop without the dead-slot mask for waves that have none (A/B: no gain)
-#endif
-#ifndef HWK_CURVE_C_VGPR
-#define HWK_CURVE_C_VGPR 0        // 1: c1, c2 of z = c1 W - c2 y in vector registers too (A/B: no gain)
-#endif
-#ifndef HWK_CURVE_E_VGPR
-#define HWK_CURVE_E_VGPR 0
-#endif
-#if HWK_CURVE_E2_VGPR
     float e2v;
     asm volatile("v_mov_b32 %0, %1" : "=v"(e2v) : "s"(a.e2));
-#else
-    const float e2v = a.e2;
-#endif
-#if HWK_CURVE_C_VGPR
-    float c1v, c2v;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(c1v) : "s"(a.c1));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(c2v) : "s"(a.c2));
-#else
     const float c1v = a.c1, c2v = a.c2;
-#endif
-#if HWK_CURVE_E_VGPR
-    float e1v;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(e1v) : "s"(a.e));
-#else
     const float e1v = a.e;
-#endif
 
     for (int it = 0; it < a.iters; it++) {
         PhiloxPath pp[P];
@@ -1422,15 +1305,11 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
         for (int q = 0; q < P; q++) uhi = philox_uniform_hi(pp[q], a2s[q]) && uhi;
         // Dead slots (pair index >= n_pairs) exist only in the last, ragged pass of the last workgroups; their contributions are
         // multiplied by live = 0.  Experiments (profiles/r02_curve_ab.txt): skipping that multiply for waves without dead
-        // slots through a second copy of the loop (HWK_CURVE_SKIP_LIVE=1) measured no faster (0.3926 vs 0.3909 ms), and a
+        // slots through a second copy of the loop measured no faster (0.3926 vs 0.3909 ms), and a
         // per-maturity scalar branch around it 2 % slower.
-        bool any_dead = false;
-#pragma unroll
-        for (int q = 0; q < P; q++) any_dead = any_dead || __builtin_amdgcn_ballot_w64(live[q] == 0.0f) != 0;
         HWK_SETPRIO(1);
-        auto blocks = [&](auto tag, auto masked_tag) {
+        auto blocks = [&](auto tag) {
             constexpr bool UHI = decltype(tag)::value;
-            constexpr bool MASKED = decltype(masked_tag)::value;
             int to_event = half_stride, m = 0;         // half blocks until the next maturity
             for (int j = 0; j < nblk; j++) {
                 const int ev = to_event <= 2 ? to_event : 0;               // 1: after the first half, 2: after the second
@@ -1438,8 +1317,7 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
                 auto contribute = [&](int q) {
                     const float z = __builtin_fmaf(c1v, W[q], -c2v * y[q]);
                     const float c = hw_exp2(z) + hw_exp2(-z);              // market_data.cuh:60
-                    if constexpr (MASKED) accq = q == 0 ? live[q] * c : __builtin_fmaf(live[q], c, accq);
-                    else accq = q == 0 ? c : accq + c;
+                    accq = q == 0 ? live[q] * c : __builtin_fmaf(live[q], c, accq);
                 };
 #pragma unroll
                 for (int q = 0; q < P; q++) {
@@ -1469,16 +1347,8 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
                 to_event = ev ? half_stride - (2 - ev) : to_event - 2;
             }
         };
-#if HWK_CURVE_SKIP_LIVE
-        if (!any_dead) {
-            if (uhi) blocks(std::true_type{}, std::false_type{});
-            else blocks(std::false_type{}, std::false_type{});
-        } else
-#endif
-        {
-            if (uhi) blocks(std::true_type{}, std::true_type{});
-            else blocks(std::false_type{}, std::true_type{});
-        }
+        if (uhi) blocks(std::true_type{});
+        else blocks(std::false_type{});
         HWK_SETPRIO(0);
         slots.finish(a.n_mat);
     }
