@@ -219,7 +219,10 @@ int  hw_get_kernel_info(hw_ctx* ctx, const char* kernel /* "zbc" | "zbc_ref" | "
  * devices with identical parameters and market curves.  Each call shards the paths by global id
  * (context g gets a contiguous block); one persistent host thread per device (started by hw_comm_create)
  * enqueues that device's shard and ONE ncclAllReduce on the device's stream (RCCL over xGMI; librccl.so.1 is
- * loaded at hw_comm_create, the library itself does not link it) and waits for it.  wall_ms: host wall time from the first launch to the reduced result. */
+ * loaded at hw_comm_create, the library itself does not link it) and waits for it.  wall_ms: host wall time from the first launch to the reduced result.
+ * Errors: a request is checked against EVERY context on the calling thread before any device is given work (a device
+ * that refused its shard would leave the others waiting in the all-reduce); failures found by a worker afterwards
+ * (HIP / RCCL errors, launch geometry) come back as "device <id>: <text>" through hw_last_error(). */
 typedef struct hw_comm hw_comm;
 int  hw_comm_create(int32_t n, hw_ctx* const* ctxs, hw_comm** out);
 /* The same with a choice of how the shards' sums are combined: HW_COMM_RCCL (what hw_comm_create does) or
