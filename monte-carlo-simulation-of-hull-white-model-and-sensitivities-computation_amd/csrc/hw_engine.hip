@@ -439,12 +439,13 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
         c->scale_valid = true;
     }
 
-    // float, whole Philox blocks, maturities on half-block boundaries: the blocked kernel, P pairs per thread
+    // whole Philox blocks, maturities on half-block boundaries: the blocked kernel, P pairs per thread
     // (P = 4 / 2 once the batch still fills the chip's 8 waves per SIMD twice over: measured, one round of fat
     // threads is no faster than two rounds of thin ones)
-    // (the (y, W) form needs (1 - e) sqrt(n_steps) >= 0.05, see ou_walk)
-    if (std::is_same<REAL, float>::value && p.n_steps % 4 == 0 && stride % 2 == 0 && stride >= 4 && !c->curve_generic &&
-        (1.0 - (double)(float)k.e) * std::sqrt((double)p.n_steps) >= 0.05) {
+    // (in float the (y, W) form needs (1 - e) sqrt(n_steps) >= 0.05, see ou_walk; in double the division is harmless)
+    constexpr bool kDouble = std::is_same<REAL, double>::value;
+    if (p.n_steps % 4 == 0 && stride % 2 == 0 && stride >= 4 && !c->curve_generic &&
+        (kDouble || (1.0 - (double)(float)k.e) * std::sqrt((double)p.n_steps) >= 0.05)) {
         const int64_t resident = (int64_t)c->prop.multiProcessorCount * 2048;
         int P = n_pairs >= 8 * resident ? 4 : n_pairs >= 4 * resident ? 2 : 1;   // keep >= 2 rounds of waves
         if (const char* m = getenv("HWMC_CURVE_P")) { const int v = atoi(m); if (v == 1 || v == 2 || v == 4) P = v; }   // tools/curve_p_probe.py
@@ -464,13 +465,16 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
         a.e2 = a.e * a.e;
         a.c1 = (float)(cz * inv);
         a.c2 = (float)(cz * ((double)a.e * inv + 0.5));
+        a.e2_d = k.e * k.e;                                     // REAL = double: from the double e
+        a.c1_d = cz / (1.0 - k.e);
+        a.c2_d = cz * (k.e / (1.0 - k.e) + 0.5);
         const size_t lds = (size_t)(g.block / 64) * hwk::maturity_groups(n_mat) * hwk::kWave * sizeof(double);
         if (lds > 64 * 1024)
             return fail(HW_E_INVALID, "n_mat = %d needs %zu B of LDS per workgroup at block size %d (limit 65536): use a smaller block", n_mat, lds, g.block);
         prof_mark(c, st, 0);
-        if (P == 4) hipLaunchKernelGGL(hwk::zcb_curve_blocked_kernel<4>, dim3(g.grid), dim3(g.block), lds, st, a, c->d_partials);
-        else if (P == 2) hipLaunchKernelGGL(hwk::zcb_curve_blocked_kernel<2>, dim3(g.grid), dim3(g.block), lds, st, a, c->d_partials);
-        else hipLaunchKernelGGL(hwk::zcb_curve_blocked_kernel<1>, dim3(g.grid), dim3(g.block), lds, st, a, c->d_partials);
+        if (P == 4) hipLaunchKernelGGL((hwk::zcb_curve_blocked_kernel<4, REAL>), dim3(g.grid), dim3(g.block), lds, st, a, c->d_partials);
+        else if (P == 2) hipLaunchKernelGGL((hwk::zcb_curve_blocked_kernel<2, REAL>), dim3(g.grid), dim3(g.block), lds, st, a, c->d_partials);
+        else hipLaunchKernelGGL((hwk::zcb_curve_blocked_kernel<1, REAL>), dim3(g.grid), dim3(g.block), lds, st, a, c->d_partials);
         prof_mark(c, st, 1);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(n_mat), dim3(256), 0, st, (const double*)c->d_partials,
@@ -1057,7 +1061,7 @@ int hw_get_kernel_info(hw_ctx* c, const char* kernel, hw_kernel_info* out)
     else if (!strcmp(kernel, "zcb"))
         fn = f64 ? (const void*)hwk::zcb_curve_kernel<double> : (const void*)hwk::zcb_curve_kernel<float>;
     else if (!strcmp(kernel, "zcb_blocked"))
-        fn = (const void*)hwk::zcb_curve_blocked_kernel<1>;
+        fn = f64 ? (const void*)hwk::zcb_curve_blocked_kernel<1, double> : (const void*)hwk::zcb_curve_blocked_kernel<1, float>;
     else if (!strcmp(kernel, "vega"))
         fn = f64 ? (const void*)hwk::vega_pathwise_kernel<double, 1> : (const void*)hwk::vega_pathwise_kernel<float, 1>;
     else

@@ -1253,12 +1253,19 @@ struct ZcbBlockedArgs {
     int32_t n_steps, n_mat, stride, iters;
     float e, e2, c1, c2;
     unsigned long long* stamps;     // nullptr, or the timeline buffer (WorkgroupStamp)
+    double e2_d, c1_d, c2_d;        // REAL = double: the same constants in double (e^2, c1, c2 from the double e)
 };
 
-template <int P>
+// REAL = double (the double engine): the state (y, W) is carried in double -- the two half-block inputs s (e sin + cos)
+// and s (sin + cos) are formed in float from the raw Box-Muller parts, as in the double stepper of ou_walk, converted
+// once and accumulated with one v_fma_f64 / v_add_f64 each; z = c1 W - c2 y is formed in double and rounded to float
+// for the two v_exp_f32 (their own error, <= 1 ulp of float and unbiased, is far below the 2e-6 floor the float normals
+// set for the double engine); maturity sums as in the float kernel (rows of 16 in float, then double).
+template <int P, typename REAL = float>
 __global__ void __launch_bounds__(1024)
 zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
 {
+    constexpr bool kDouble = std::is_same<REAL, double>::value;
     extern __shared__ double s_tiles[];                // [nwaves][groups][64], see MaturityTree
     WorkgroupStamp stamp;
     stamp.begin(a.stamps);
@@ -1289,15 +1296,16 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
 
     for (int it = 0; it < a.iters; it++) {
         PhiloxPath pp[P];
-        float y[P], W[P], live[P];
+        REAL y[P], W[P];
+        float live[P];
 #pragma unroll
         for (int q = 0; q < P; q++) {
             int64_t p = t + ((int64_t)it * P + q) * T;
             live[q] = p < a.n_pairs ? 1.0f : 0.0f;
             if (p >= a.n_pairs) p = 0;
             pp[q] = philox_path(key, a.path_offset + (uint64_t)p);
-            y[q] = 0.0f;
-            W[q] = 0.0f;
+            y[q] = 0;
+            W[q] = 0;
         }
         uint32_t a2s[P];
         bool uhi = true;
@@ -1315,7 +1323,9 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
                 const int ev = to_event <= 2 ? to_event : 0;               // 1: after the first half, 2: after the second
                 float accq;                                                // assigned by q == 0 of an event block
                 auto contribute = [&](int q) {
-                    const float z = __builtin_fmaf(c1v, W[q], -c2v * y[q]);
+                    float z;
+                    if constexpr (kDouble) z = (float)__builtin_fma(a.c1_d, W[q], -a.c2_d * y[q]);
+                    else z = __builtin_fmaf(c1v, W[q], -c2v * y[q]);
                     const float c = hw_exp2(z) + hw_exp2(-z);              // market_data.cuh:60
                     accq = q == 0 ? live[q] * c : __builtin_fmaf(live[q], c, accq);
                 };
@@ -1326,20 +1336,40 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
                     float s0, sn0, cs0, s1, sn1, cs1;
                     box_muller_parts(w0, w1, s0, sn0, cs0);
                     box_muller_parts(w2, w3, s1, sn1, cs1);
-                    y[q] = __builtin_fmaf(e2v, y[q], s0 * __builtin_fmaf(e1v, sn0, cs0));
-                    W[q] = __builtin_fmaf(s0, sn0 + cs0, W[q]);
                     // ev is wave-uniform: these are scalar branches.  The empty volatile asm keeps the compiler from
                     // if-converting them (it did: both pairs of v_exp_f32 ran in every event block and a v_cndmask
                     // picked one -- two transcendentals = 16 issue cycles wasted per maturity).
-                    if (ev == 1) {
-                        asm volatile("" ::: "memory");
-                        contribute(q);
-                    }
-                    y[q] = __builtin_fmaf(e2v, y[q], s1 * __builtin_fmaf(e1v, sn1, cs1));
-                    W[q] = __builtin_fmaf(s1, sn1 + cs1, W[q]);
-                    if (ev == 2) {
-                        asm volatile("" ::: "memory");
-                        contribute(q);
+                    if constexpr (kDouble) {
+                        const float t0 = s0 * __builtin_fmaf(e1v, sn0, cs0), t1 = s1 * __builtin_fmaf(e1v, sn1, cs1);
+                        const float u0 = s0 * (sn0 + cs0), u1 = s1 * (sn1 + cs1);
+                        if (ev == 1) {                                     // a maturity between the two halves
+                            asm volatile("" ::: "memory");
+                            y[q] = __builtin_fma(a.e2_d, y[q], (double)t0);
+                            W[q] += (double)u0;
+                            contribute(q);
+                            y[q] = __builtin_fma(a.e2_d, y[q], (double)t1);
+                            W[q] += (double)u1;
+                        } else {                                           // whole block, as the double stepper of ou_walk:
+                            y[q] = __builtin_fma(a.e2_d, __builtin_fma(a.e2_d, y[q], (double)t0), (double)t1);   // 3 cvt + 2 fma + 1 add
+                            W[q] += (double)(u0 + u1);
+                            if (ev == 2) {
+                                asm volatile("" ::: "memory");
+                                contribute(q);
+                            }
+                        }
+                    } else {
+                        y[q] = __builtin_fmaf(e2v, y[q], s0 * __builtin_fmaf(e1v, sn0, cs0));
+                        W[q] = __builtin_fmaf(s0, sn0 + cs0, W[q]);
+                        if (ev == 1) {
+                            asm volatile("" ::: "memory");
+                            contribute(q);
+                        }
+                        y[q] = __builtin_fmaf(e2v, y[q], s1 * __builtin_fmaf(e1v, sn1, cs1));
+                        W[q] = __builtin_fmaf(s1, sn1 + cs1, W[q]);
+                        if (ev == 2) {
+                            asm volatile("" ::: "memory");
+                            contribute(q);
+                        }
                     }
                 }
                 m += ev != 0;

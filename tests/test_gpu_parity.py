@@ -566,10 +566,27 @@ def test_zcb_curve_maturity_counts(hwmc_mod, oracle_mod, monkeypatch, n_mat, n_s
     monkeypatch.setenv("HWMC_CURVE_GENERIC", "1")
     with hwmc_mod.HullWhiteEngine(p, device=0) as g:
         np.testing.assert_allclose(g.simulate_zcb(n, 17), want, rtol=REL_F32)
+    # the double engine: the per-step kernel (HWMC_CURVE_GENERIC still set) and the blocked kernel with its state in double
     pd = hwmc_mod.default_params("readme", n_steps=n_steps, n_mat=n_mat, precision="f64")
     od = oracle_mod.Oracle("readme", n_steps=n_steps, n_mat=n_mat, precision="f64")
+    want64 = od.zcb_curve(n, 17)
     with hwmc_mod.HullWhiteEngine(pd, device=0) as d:
-        np.testing.assert_allclose(d.simulate_zcb(n, 17), od.zcb_curve(n, 17), rtol=REL_F64)
+        np.testing.assert_allclose(d.simulate_zcb(n, 17), want64, rtol=REL_F64)
+    monkeypatch.delenv("HWMC_CURVE_GENERIC")
+    for P in ("1", "2", "4"):
+        monkeypatch.setenv("HWMC_CURVE_P", P)
+        with hwmc_mod.HullWhiteEngine(pd, device=0) as d:
+            np.testing.assert_allclose(d.simulate_zcb(n, 17), want64, rtol=REL_F64, err_msg="f64 P=%s" % P)
+            d.set_launch(block_size=64, max_blocks_per_cu=0)
+            np.testing.assert_allclose(d.simulate_zcb(n, 17), want64, rtol=REL_F64)
+            d.set_launch(block_size=128, max_blocks_per_cu=1)
+            cap = d.device_info()["compute_units"] * 128
+            big = 2 * cap * int(P) + 333
+            got_big = d.simulate_zcb(big, 5)
+            assert got_big[0] == 2.0 * big
+            halves = d.simulate_zcb(cap * int(P), 5) + d.simulate_zcb(big - cap * int(P), 5, path_offset=cap * int(P))
+            np.testing.assert_allclose(got_big[1:], halves[1:], rtol=1e-6)
+    monkeypatch.delenv("HWMC_CURVE_P")
 
 
 def test_zcb_curve_blocked_equals_generic_at_full_size(hwmc_mod, oracle_mod, monkeypatch):
@@ -591,6 +608,36 @@ def test_zcb_curve_blocked_equals_generic_at_full_size(hwmc_mod, oracle_mod, mon
         np.testing.assert_allclose(e.simulate_zcb(1 << 20, 99, sigma=sg), o.zcb_curve(1 << 20, 99, sigma=sg), rtol=REL_F32)
     e.close()
     g.close()
+
+
+def test_zcb_curve_f64_blocked_equals_generic_at_full_size(hwmc_mod, oracle_mod, monkeypatch):
+    """The double engine's curve: the blocked kernel (state y, W in double, half Philox blocks, contributions through the
+    float v_exp_f32, transposed reduction) against the per-step double kernel (double exp2, per-maturity slots in double)
+    at every size class (P = 1, 2, 4), against the double oracle at 2^16 pairs, against the float engine at 2^20 pairs
+    (same draws: float and double state differ by float rounding only), and under weak mean reversion, where the FLOAT
+    engine must leave the (y, W) form but the double one need not."""
+    p = hwmc_mod.default_params("readme", precision="f64")
+    monkeypatch.setenv("HWMC_CURVE_GENERIC", "1")
+    g = hwmc_mod.HullWhiteEngine(p, device=0)
+    monkeypatch.delenv("HWMC_CURVE_GENERIC")
+    e = hwmc_mod.HullWhiteEngine(p, device=0)
+    assert e.kernel_info("zcb_blocked")["scratch_bytes"] == 0
+    for n in (1000, (1 << 18) + 512, (1 << 20) + 77, 1 << 21, 1 << 22):
+        a, b = e.simulate_zcb(n, 99), g.simulate_zcb(n, 99)
+        assert a[0] == b[0] == 2.0 * n
+        np.testing.assert_allclose(a[1:], b[1:], rtol=2e-7, err_msg="n = %d" % n)
+    o = oracle_mod.Oracle("readme", precision="f64")
+    np.testing.assert_allclose(e.simulate_zcb(1 << 16, 5), o.zcb_curve(1 << 16, 5), rtol=REL_F64)
+    with hwmc_mod.HullWhiteEngine(hwmc_mod.default_params("readme"), device=0) as e32:
+        np.testing.assert_allclose(e32.simulate_zcb(1 << 20, 99), e.simulate_zcb(1 << 20, 99), rtol=REL_F32)
+    e.close()
+    g.close()
+    pw = hwmc_mod.default_params("readme", precision="f64")
+    pw.a = 0.05                                                                    # (1 - e) sqrt(1000) = 0.016 < 0.05
+    ow = oracle_mod.Oracle("readme", precision="f64")
+    ow.m.a = 0.05
+    with hwmc_mod.HullWhiteEngine(pw, device=0) as ew:
+        np.testing.assert_allclose(ew.simulate_zcb(3000, 8), ow.zcb_curve(3000, 8), rtol=REL_F64)
 
 
 def test_full_size_properties_of_the_multi_gpu_shares(setup, hwmc_mod):

@@ -93,7 +93,7 @@ def test_curve_kernel_reduces_sixteen_maturities_together(listing):
     (MaturityTree) spends 2 v_cndmask + 1 v_add_f32_dpp per merge, four merge levels in the loop body, the pending
     vectors updated in place (no v_mov storm around the asm: at most 6 v_mov in the whole loop body of the P = 1 kernel),
     and exactly one pair of v_exp_f32 per half-block event."""
-    lines, meta = _kernel(listing, "zcb_curve_blocked_kernelILi1E")
+    lines, meta = _kernel(listing, "zcb_curve_blocked_kernelILi1EfE")
     assert meta["ScratchSize"] == 0 and meta["Occupancy"] == 8 and meta["NumVgprs"] <= 56
     body = [l.strip().split()[0] for l in lines if l.strip() and not l.strip().startswith((";", "."))]
     c = Counter(body)
@@ -173,7 +173,7 @@ def _hot_loops_x2(lines):
 
 
 def test_other_kernels_have_no_scratch_and_full_occupancy(listing):
-    for pat in ("vega_pathwise_kernelIfLi1E", "zcb_curve_blocked_kernelILi1E", "zcb_curve_blocked_kernelILi2E",
+    for pat in ("vega_pathwise_kernelIfLi1E", "zcb_curve_blocked_kernelILi1EfE", "zcb_curve_blocked_kernelILi2EfE",
                 "zbc_superposed_kernelIfLi2ELi1E", "zbc_reference_kernelILi0E"):
         _, meta = _kernel(listing, pat)
         assert meta["ScratchSize"] == 0 and meta["Occupancy"] == 8, (pat, meta)
@@ -181,5 +181,5 @@ def test_other_kernels_have_no_scratch_and_full_occupancy(listing):
     assert meta["ScratchSize"] == 0 and meta["Occupancy"] >= 7, meta
     # four pairs per thread carry 4 x (4 Philox words + y + W + live): 74 registers, 6 waves per SIMD -- measured
     # faster than two pairs at 8 waves all the same (tools/curve_p_probe.py); it must not spill or drop further
-    _, meta = _kernel(listing, "zcb_curve_blocked_kernelILi4E")
+    _, meta = _kernel(listing, "zcb_curve_blocked_kernelILi4EfE")
     assert meta["ScratchSize"] == 0 and meta["Occupancy"] >= 6 and meta["NumVgprs"] <= 80, meta
