@@ -387,7 +387,17 @@ __device__ __forceinline__ void normal4_prio(const PhiloxKey& k, const PhiloxPat
 // small math helpers
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float  hw_exp2(float x)  { return __builtin_amdgcn_exp2f(x); }
-__device__ __forceinline__ double hw_exp2(double x) { return exp2(x); }
+// exp2 of a double through the float unit: 2^x = 2^xf (1 + ln2 (x - xf)) with xf = x rounded to float (|x - xf| <=
+// 2^-25 |x|: the first-order term is exact to 1e-15).  The result carries v_exp_f32's own error (<= 1 ulp of float,
+// ~6e-8 relative, unbiased) -- the double engine consumes float normals from the same hardware units (|error| <= 2e-5
+// absolute on a normal), so a correctly rounded double exp2 (ocml: ~200 issue cycles a call,
+// measured as +5.6 % on the three-scenario kernel at 2^20 pairs) would buy nothing.  |x| < 126 on this path (x ~ O(1)).
+__device__ __forceinline__ double hw_exp2(double x)
+{
+    const float xf = (float)x;
+    const double e = (double)__builtin_amdgcn_exp2f(xf);
+    return __builtin_fma(e * 0.69314718055994531, x - (double)xf, e);
+}
 __device__ __forceinline__ float  hw_fma(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double hw_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float  hw_max0(float a)  { return fmaxf(a, 0.0f); }
