@@ -73,9 +73,10 @@ def test_zbc_f64_hot_loop_keeps_its_instruction_budget(listing):
     per-step form it replaced had 4 + 4 + 4), the same 16 multiplies, 8 transcendentals and 4 conversions as the float
     loop, and at most 30 single-rate instructions: bench.py's VALU_MODEL["superposed_f64"] = 30 / 26 / 8."""
     lines, meta = _kernel(listing, "zbc_superposed_kernelIdLi1ELi1E")
-    # 64 VGPRs, but 106 SGPRs (the double constants take two each): 7 waves per SIMD.  Measured at the issue bound all
-    # the same (0.204 ms at 2^20 pairs = the float kernel's 0.187 ms x 228 / 208 model cycles).
-    assert meta["ScratchSize"] == 0 and meta["Occupancy"] >= 7 and meta["NumVgprs"] <= 64
+    # 62 VGPRs since the epilogue's exp2 goes through the float unit (hw_exp2(double); ocml's exp2 cost registers and
+    # 106 SGPRs: 7 waves per SIMD then): 8 waves per SIMD.  0.202 ms at 2^20 pairs = the float kernel's 0.187 ms x 228 / 208
+    # model cycles less what the shorter epilogue saves.
+    assert meta["ScratchSize"] == 0 and meta["Occupancy"] == 8 and meta["NumVgprs"] <= 64
     loops = _hot_loops(lines)
     best = min(loops, key=lambda c: (c["v_mad_u64_u32"], sum(v for k, v in c.items() if k.startswith("v_"))))
     trans = ("v_log_f32_e32", "v_sqrt_f32_e64", "v_sqrt_f32_e32", "v_sin_f32_e32", "v_cos_f32_e32")
@@ -183,3 +184,8 @@ def test_other_kernels_have_no_scratch_and_full_occupancy(listing):
     # faster than two pairs at 8 waves all the same (tools/curve_p_probe.py); it must not spill or drop further
     _, meta = _kernel(listing, "zcb_curve_blocked_kernelILi4EfE")
     assert meta["ScratchSize"] == 0 and meta["Occupancy"] >= 6 and meta["NumVgprs"] <= 80, meta
+    # the double engine: state in double costs registers (y, W take two each) but no occupancy class
+    for pat, occ in (("zcb_curve_blocked_kernelILi1EdE", 8), ("zcb_curve_blocked_kernelILi2EdE", 8), ("zcb_curve_blocked_kernelILi4EdE", 6),
+                     ("vega_pathwise_kernelIdLi1E", 8), ("zbc_superposed_kernelIdLi3ELi1E", 6), ("zcb_curve_kernelIdE", 8)):
+        _, meta = _kernel(listing, pat)
+        assert meta["ScratchSize"] == 0 and meta["Occupancy"] >= occ, (pat, meta)
