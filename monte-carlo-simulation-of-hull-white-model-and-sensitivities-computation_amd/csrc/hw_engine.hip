@@ -227,18 +227,20 @@ Geometry geometry(const hw_ctx* c, int64_t n_units, int ilp, bool wide_rows = fa
 
 // Pairs (paths) in flight per thread of the superposed ZBC / Vega kernels.  Two -- their Philox blocks interleaved
 // (philox_block_prio_x2) -- halve the number of waves and with it the per-wave work outside the time loop (key setup,
-// payoff epilogue, the five DPP reductions in double: ~700 issue cycles a wave).  Measured (tools/ilp_probe.py): +1.0 % at
-// 2^22 pairs and +1.2 % at 2^26 on the 1000-step grid (500 executed steps), nothing below four chip-fills of pairs (the
-// batch then fills the chip only once or twice with half as many waves) and nothing at 2000 executed steps (42.69 vs
-// 42.63 ms at 2^26 pairs: the per-wave overhead is four times smaller there).  So: two from four chip-fills up when the path
-// has at most 1024 steps, in the float (y, W) loop; one for the double engine, the multi-scenario kernel and the per-step
-// fallback under weak mean reversion.  hw_set_launch(pairs_in_flight = 1 | 2) overrides, -1 returns to automatic.
-int effective_ilp(const hw_ctx* c, int64_t n_units, int n_steps, double e, int n_scen)
+// payoff epilogue, the five DPP reductions in double: ~700 issue cycles a wave).  Measured (tools/ilp_probe.py, one launch
+// at a time): +1.0 % at 2^22 pairs and +1.2 % at 2^26 on the 1000-step grid (500 executed steps), nothing at 2000 executed
+// steps (42.69 vs 42.63 ms at 2^26 pairs: the per-wave overhead is four times smaller there).  Where the rule starts was
+// re-measured in the loop bench.py times (tools/ilp_pipeline_probe.py, K = 20 calls, two queues / one queue): 2^20 pairs
+// +1.9 % / +0.4 %, 2^21 +1.4 % / +1.0 %, 2^19 +1.1 % / -0.9 %, 2^18 -3 % / -9 % (half a chip-fill of waves).  So: two from
+// TWO chip-fills of pairs up (2^20 on 256 CUs: one full round of 8 waves per SIMD) when the path has at most 1024 steps, in the
+// float (y, W) loop; one for the double engine, the multi-scenario kernel and the per-step fallback under weak mean
+// reversion.  hw_set_launch(pairs_in_flight = 1 | 2) overrides, -1 returns to automatic.
+int effective_ilp(const hw_ctx* c, int64_t n_units, int n_steps, double e, int n_scen, int min_fills = 2)
 {
     if (c->ilp == 1 || c->ilp == 2) return c->ilp;
     if (c->p.precision != HW_F32 || n_scen != 1 || n_steps > 1024) return 1;
     if ((1.0 - (double)(float)e) * std::sqrt((double)n_steps) < 0.05) return 1;       // the guard of ou_walk's (y, W) form
-    return n_units >= (int64_t)4 * 2048 * c->prop.multiProcessorCount ? 2 : 1;
+    return n_units >= (int64_t)min_fills * 2048 * c->prop.multiProcessorCount ? 2 : 1;
 }
 
 // second launch of the default two-launch finish (no-op when the kernel finished in-launch)
@@ -526,7 +528,9 @@ int launch_vega(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset,
         c->vega_key_steps = n_steps_S1;
     }
 
-    const int ilp = effective_ilp(c, n_paths, n_steps_S1, s.k.e, 1);
+    // (the Vega kernel alone on the chip at 2^20 paths: 0.1861 ms with two paths per thread against 0.1846 with one --
+    // its launches are not pipelined by any caller, so it keeps the one-launch-at-a-time threshold of four chip-fills)
+    const int ilp = effective_ilp(c, n_paths, n_steps_S1, s.k.e, 1, 4);
     const Geometry g = geometry(c, n_paths, ilp);
     if ((int64_t)g.grid * n_runs > ((int64_t)1 << 22)) return fail(HW_E_INVALID, "n_runs x workgroups per run exceeds 2^22");
     const int total_grid = g.grid * n_runs;
@@ -1020,7 +1024,7 @@ int hw_get_launch_geometry(hw_ctx* c, const char* kernel, int64_t n_units, int32
     const int n_half = std::max(1, hw::steps_to(c->p, c->p.T_final / 2.0));
     const int ilp_auto = effective_ilp(c, n_units, n_half, hw::step_constants(c->p, c->p.sigma).e, 1);
     if (!strcmp(kernel, "zbc") || !strcmp(kernel, "zbc_ref")) { g = geometry(c, n_units, !strcmp(kernel, "zbc") ? ilp_auto : 1); row = 5 * 8; }
-    else if (!strcmp(kernel, "vega")) { g = geometry(c, n_units, ilp_auto); row = 8; }
+    else if (!strcmp(kernel, "vega")) { g = geometry(c, n_units, effective_ilp(c, n_units, n_half, hw::step_constants(c->p, c->p.sigma).e, 1, 4)); row = 8; }
     else if (!strcmp(kernel, "zcb") || !strcmp(kernel, "zcb_blocked")) {
         int P = 1;
         if (!strcmp(kernel, "zcb_blocked")) {

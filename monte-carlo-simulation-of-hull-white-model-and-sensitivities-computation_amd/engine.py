@@ -143,7 +143,9 @@ class HullWhiteEngine:
         b, g, it, pb = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int64(0)
         L.check(self.lib.hw_get_launch_geometry(self._ctx, kernel.encode(), int(n_units), C.byref(b), C.byref(g),
                                                 C.byref(it), C.byref(pb)))
-        return {"block": b.value, "grid": g.value, "iters": it.value, "partial_bytes": pb.value}
+        slots = b.value * g.value * it.value
+        return {"block": b.value, "grid": g.value, "iters": it.value, "partial_bytes": pb.value,
+                "units_per_thread": max(1, -(-int(n_units) // slots)) if slots else 1}   # 2: two pairs per thread (effective_ilp)
 
     def profile_clock_mhz(self):
         """Shader clock held during the last profiled superposed-ZBC launch (in-kernel probe)."""

@@ -57,7 +57,7 @@ def test_bench_flag_combinations(args, env):
     # the kernels cannot occupy the chip for longer per step than a step lasts (2 % for timer granularity)
     assert d["roofline"]["kernel_ms_per_step_in_timed_region"] <= 1.02 * d["ms_per_step"]
     g = d["roofline"]["launch_geometry"]
-    assert g["grid"] * g["block"] * g["iters"] >= d["config"]["pairs_per_gpu"]
+    assert g["grid"] * g["block"] * g["iters"] * g["units_per_thread"] >= d["config"]["pairs_per_gpu"] and g["units_per_thread"] in (1, 2)
     assert d["roofline"]["algorithmic_bytes_per_launch"] == g["partial_bytes"] + 40
     if env:
         assert d["multi_gpu"]["single_call_ms"] > 0 and len(d["multi_gpu"]["per_rank_kernel_ms"]) == 1

@@ -138,11 +138,11 @@ def test_zbc_lds_table_variant_and_launch_knobs(setup, hwmc_mod):
 
 
 def test_two_pairs_in_flight_interleaved_blocks(setup, hwmc_mod):
-    """pairs_in_flight = 2 (the engine's automatic choice from four chip-fills of pairs up): the Philox blocks of a
+    """pairs_in_flight = 2 (the engine's automatic choice from two chip-fills of pairs up): the Philox blocks of a
     thread's two pairs run in lockstep (philox_block_prio_x2).  Per pair the arithmetic is the one-pair loop's, so the
     sums must equal the one-pair launch to 1e-13 (only the grouping of the double additions differs) and the oracle to
     1e-5 -- ragged counts, ids straddling a multiple of 2^32 (the per-lane round-2 multiply), 1..3 tail steps, the Vega
-    kernel, batched runs, and the automatic switch at 2^22 pairs."""
+    kernel, batched runs, and the automatic switch at two chip-fills (2^20 pairs on 256 CUs)."""
     e, o, P, f = setup("head")
     try:
         for n, off in ((5000, 0), (70_001, 123), (4097, (1 << 32) - 2000), (300, (5 << 32) - 150)):
@@ -161,10 +161,10 @@ def test_two_pairs_in_flight_interleaved_blocks(setup, hwmc_mod):
         runs = e.simulate_ZBC_runs(6000, 1234, n_runs=3)
         for k in range(3):
             assert np.array_equal(runs[k], e.simulate_ZBC_control_variate(6000, 1234 + k * 12345))
-        # automatic: one pair below four chip-fills, two from there on -- same sums either way
+        # automatic: one pair below two chip-fills, two from there on -- same sums either way
         e.set_launch(pairs_in_flight=-1)
         cus = e.device_info()["compute_units"]
-        n_big = 4 * 2048 * cus + 333
+        n_big = 2 * 2048 * cus + 333
         assert e.launch_geometry("zbc", n_big)["grid"] * 2 * 512 >= n_big > e.launch_geometry("zbc", n_big)["grid"] * 512
         assert e.launch_geometry("zbc", n_big - 1000)["grid"] * 512 >= n_big - 1000
         auto = e.simulate_ZBC_control_variate(n_big, 3)

@@ -139,7 +139,7 @@ def test_reference_stepper_loop_walks_a_whole_philox_block_per_trip(listing):
 
 
 def test_two_pairs_in_flight_loop_is_interleaved_and_unpacked(listing):
-    """zbc_superposed_kernel<float, 1, 2> (two pairs per thread, used from four chip-fills of pairs up): exactly twice the
+    """zbc_superposed_kernel<float, 1, 2> (two pairs per thread, used from two chip-fills of pairs up): exactly twice the
     one-pair loop's instructions -- 32 multiplies, 16 transcendentals -- and NO v_pk_* / v_mov in it (-fno-slp-vectorize:
     the SLP vectoriser otherwise packs the two pairs' steps and pays 12 v_mov per block for it)."""
     lines, meta = _kernel(listing, "zbc_superposed_kernelIfLi1ELi2E")

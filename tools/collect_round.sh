@@ -20,7 +20,7 @@ step "stress f32" 200 python tools/time_kernels.py --log2 26 --grid-steps 4000 -
 step "stress f64" 200 python tools/time_kernels.py --log2 26 --grid-steps 4000 --reps 3 --precision f64 > "$OUT/stress_f64.txt" 2>&1
 step "curve event cost" 200 python tools/curve_event_cost.py --P 1 > "$OUT/curve_event_cost_p1.txt" 2>&1
 step "readme pin" 200 python tools/readme_pin_report.py > "$OUT/readme_pin.txt" 2>&1
-( for k in zbc zcb1; do timeout -k 5 60 tools/bin/timeline_probe 20 512 $k || exit 1; done ) > "$OUT/timeline_probe.txt" 2>&1 || { echo "timeline failed"; exit 1; }
+( for k in zbc zbc1 zcb1; do timeout -k 5 60 tools/bin/timeline_probe 20 512 $k || exit 1; done ) > "$OUT/timeline_probe.txt" 2>&1 || { echo "timeline failed"; exit 1; }
 step "bench sizes" 600 python tools/bench_sizes.py > "$OUT/bench_size_table.txt" 2>&1
 echo "== rocprofv3 passes"
 timeout -k 10 900 bash tools/profile_round.sh "$TAG" > "$OUT/profile_round.log" 2>&1 || { echo "profile_round failed"; tail -5 "$OUT/profile_round.log"; exit 1; }

@@ -23,7 +23,8 @@ def newest(pattern):
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
-    want = sys.argv[3] if len(sys.argv) > 3 else "zbc_superposed_kernel<float, 1, 1>"
+    # the float ZBC kernel with two pairs per thread: what the engine launches for the default bench (2^20 pairs: effective_ilp)
+    want = sys.argv[3] if len(sys.argv) > 3 else "zbc_superposed_kernel<float, 1, 2>"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {"command": open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else None,
            "kernel": want, "passes": {}}

@@ -14,23 +14,28 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-// The PRODUCTION kernels are launched (hwk::zbc_superposed_kernel<float,1,1> or hwk::zcb_curve_blocked_kernel<P>) with
+// The PRODUCTION kernels are launched (hwk::zbc_superposed_kernel<float,1,ILP> or hwk::zcb_curve_blocked_kernel<P>) with
 // their optional `stamps` argument set; the engine itself always passes nullptr there.
-//   timeline_probe [log2 pairs = 20] [threads per workgroup = 512] [kernel = zbc | zcb1 | zcb2 | zcb4] [n_mat = 101]
+//   timeline_probe [log2 pairs = 20] [threads per workgroup = 512] [kernel = zbc | zbc1 | zbc2 | zcb1 | zcb2 | zcb4] [n_mat = 101]
+// zbc: pairs per thread as the engine chooses them (two from two chip-fills of pairs up); zbc1 / zbc2 force one / two.
 int main(int argc, char** argv)
 {
     using namespace hwk;
     const int log2n = argc > 1 ? atoi(argv[1]) : 20, block = argc > 2 ? atoi(argv[2]) : 512;
     const std::string kern = argc > 3 ? argv[3] : "zbc";
     const int n_mat = argc > 4 ? atoi(argv[4]) : 101;
-    const int P = kern == "zcb2" ? 2 : kern == "zcb4" ? 4 : 1;
     const long long n_pairs = 1ll << log2n;
+    const bool is_zbc = kern.rfind("zbc", 0) == 0;
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int ilp = kern == "zbc2" ? 2 : kern == "zbc1" ? 1 : (n_pairs >= 2ll * 2048 * prop.multiProcessorCount ? 2 : 1);   // effective_ilp
+    const int P = kern == "zcb2" ? 2 : kern == "zcb4" ? 4 : is_zbc ? ilp : 1;
     const int grid = (int)(n_pairs / ((long long)block * P));
-    const int n_steps = kern == "zbc" ? 500 : 1000;
+    const int n_steps = is_zbc ? 500 : 1000;
     unsigned long long* d_st;
     double *d_partials, *d_out;
     CHECK(hipMalloc(&d_st, (size_t)grid * 16));
-    CHECK(hipMalloc(&d_partials, (size_t)grid * (kern == "zbc" ? 5 : n_mat) * sizeof(double)));
+    CHECK(hipMalloc(&d_partials, (size_t)grid * (is_zbc ? 5 : n_mat) * sizeof(double)));
     CHECK(hipMalloc(&d_out, 1024 * sizeof(double)));
     const float e = 0.99004983f;
     ZbcArgs<float, 1> za{};
@@ -42,9 +47,10 @@ int main(int argc, char** argv)
     ca.e = e; ca.e2 = e * e; ca.c1 = 1.7e-2f; ca.c2 = 1.7e-2f;
     const size_t lds = (size_t)(block / 64) * maturity_groups(n_mat) * kWave * sizeof(double);
     auto launch = [&](unsigned long long seed, unsigned long long* stamps) {
-        if (kern == "zbc") {
+        if (is_zbc) {
             za.seed = seed; za.stamps = stamps;
-            hipLaunchKernelGGL((zbc_superposed_kernel<float, 1, 1>), dim3(grid), dim3(block), 0, 0, za, d_partials, (unsigned*)nullptr, d_out);
+            if (ilp == 2) hipLaunchKernelGGL((zbc_superposed_kernel<float, 1, 2>), dim3(grid), dim3(block), 0, 0, za, d_partials, (unsigned*)nullptr, d_out);
+            else hipLaunchKernelGGL((zbc_superposed_kernel<float, 1, 1>), dim3(grid), dim3(block), 0, 0, za, d_partials, (unsigned*)nullptr, d_out);
         } else {
             ca.seed = seed; ca.stamps = stamps;
             if (P == 4) hipLaunchKernelGGL(zcb_curve_blocked_kernel<4>, dim3(grid), dim3(block), lds, 0, ca, d_partials);
@@ -55,7 +61,7 @@ int main(int argc, char** argv)
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < (kern == "zbc" ? 600 : 300); i++) launch(1ull, nullptr);   // clocks up
+    for (int i = 0; i < (is_zbc ? 600 : 300); i++) launch(1ull, nullptr);   // clocks up
     CHECK(hipDeviceSynchronize());
     float ms_plain = 1e9f, ms = 0.0f;
     for (int i = 0; i < 5; i++) {                                                  // the same launch without stamps
@@ -82,9 +88,9 @@ int main(int argc, char** argv)
     std::vector<double> s2 = start, e2 = end, l2 = life;
     std::sort(s2.begin(), s2.end()); std::sort(e2.begin(), e2.end()); std::sort(l2.begin(), l2.end());
     auto pct = [&](const std::vector<double>& v, double p) { return v[(size_t)(p * (v.size() - 1))]; };
-    printf("%s: 2^%d pairs, %d-thread workgroups (%d), %d steps, %d maturities; hipEvent time of the launch %.1f us (%.1f without stamps); "
+    printf("%s (%d pair(s) per thread): 2^%d pairs, %d-thread workgroups (%d), %d steps, %d maturities; hipEvent time of the launch %.1f us (%.1f without stamps); "
            "in-kernel span first start -> last end %.1f us (stamps: us after the first workgroup started)\n",
-           kern.c_str(), log2n, block, grid, n_steps, kern == "zbc" ? 0 : n_mat - 1, ms * 1e3, ms_plain * 1e3, e2.back());
+           kern.c_str(), P, log2n, block, grid, n_steps, is_zbc ? 0 : n_mat - 1, ms * 1e3, ms_plain * 1e3, e2.back());
     printf("workgroup START : min %.1f  p10 %.1f  p50 %.1f  p90 %.1f  max %.1f\n", s2[0], pct(s2, .1), pct(s2, .5), pct(s2, .9), s2.back());
     printf("workgroup END   : min %.1f  p10 %.1f  p50 %.1f  p90 %.1f  max %.1f\n", e2[0], pct(e2, .1), pct(e2, .5), pct(e2, .9), e2.back());
     printf("workgroup LIFE  : min %.1f  p10 %.1f  p50 %.1f  p90 %.1f  max %.1f\n", l2[0], pct(l2, .1), pct(l2, .5), pct(l2, .9), l2.back());
