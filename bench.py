@@ -483,6 +483,26 @@ def main():
         extras["long_region"] = {"steps": k_long, "ms_per_step": long_ms, "value": (2 * shard_n / long_ms) / 1000.0, "unit": "M paths/s",
                                  "note": "untimed side measurement: 10 K steps between two synchronisations instead of K; the difference to "
                                          "`value` is the cost of starting and draining the two-queue pipeline once per K steps"}
+    if world == 1 and not a.no_extras and S > 1 and a.stepper == "superposed":
+        # The same K pricing calls through the LIBRARY's own pipe (hw_pipe_*: the C ABI's form of what the timed region does
+        # by hand with two contexts and a stream search): K requests in, K x 5 sums out on the host, one synchronisation.
+        with hwmc.HullWhitePipeline(p, device=local_rank, queues=S) as pipe:
+            pipe.load_market_data(P, f)
+            tuned_ms = pipe.tune(shard_n)
+            seeds = [1234 + 12345 * i for i in range(K)]
+            tp = time.perf_counter()
+            while (time.perf_counter() - tp) * 1e3 < 60.0:
+                pipe.simulate_ZBC_batch(shard_n, seeds, path_offset=offset)
+            got, ms_list = None, []
+            for _ in range(R):
+                got, ms = pipe.simulate_ZBC_batch(shard_n, seeds, path_offset=offset, return_ms=True)
+                ms_list.append(ms / K)
+            assert np.array_equal(got, sums), "hw_pipe_zbc_moments and the timed region disagree"
+            pm = float(np.median(ms_list))
+            extras["library_pipeline"] = {"api": "hw_pipe_zbc_moments", "queues": S, "steps": K, "ms_per_step": pm,
+                                          "value": (2 * shard_n / pm) / 1000.0, "unit": "M paths/s", "tuned_ms_per_step": tuned_ms,
+                                          "note": "K requests through the C ABI's pipe, host wall time inside the call (enqueue, one D2H "
+                                                  "copy of the K x 5 sums, one synchronisation), median of %d batches; sums identical to the timed region's" % R}
     if world == 1 and not a.no_extras:
         # the OTHER stepper on the same workload: the reference's per-step arithmetic verbatim vs the superposed recursion
         other = hwmc.HW_STEPPER_REFERENCE if a.stepper == "superposed" else hwmc.HW_STEPPER_SUPERPOSED

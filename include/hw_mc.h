@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HW_ABI_VERSION 2
+#define HW_ABI_VERSION 3   /* 3: + hw_pipe_* (additive) */
 
 /* error codes */
 #define HW_OK            0
@@ -213,6 +213,25 @@ int  hw_profile_clock(hw_ctx* ctx, double* shader_mhz);
 
 int  hw_get_kernel_info(hw_ctx* ctx, const char* kernel /* "zbc" | "zbc_ref" | "zcb" | "zcb_blocked" | "vega" */,
                         hw_kernel_info* out);
+
+/* ---- a stream of independent pricing calls on ONE GPU, two queues in flight -------------------------
+ * (not in the reference: its 20-run validation launches, synchronises and copies 20 times, src/2_option_pricing.cu:225-302).
+ * A launch of 2^20 pairs spends ~11 us of its ~187 us outside its kernel (dispatch, end-of-kernel release) and drains
+ * through a last round of half-empty CUs; a second launch in flight on another hardware queue fills both.  A pipe owns
+ * n_queues contexts (each with its own workspaces) and a set of candidate streams; HIP maps streams onto a few hardware
+ * queues in a way that depends on the process's history, and two streams that share a queue serialise, so hw_pipe_tune
+ * times every pair of candidates on the caller's own workload and keeps the fastest (hw_pipe_zbc_moments tunes on its
+ * first request if the caller has not).  hw_pipe_zbc_moments enqueues the n requests alternating over the queues -- every
+ * request is one full pricing call, exactly hw_zbc_moments_async -- brings the n x 5 sums back with ONE copy and
+ * synchronises once; the sums equal those of n separate hw_zbc_moments calls bit for bit.  wall_ms: host wall time of the
+ * call.  Measured at 2^20 pairs x 500 steps: ~0.174 ms per call against 0.190 ms for synchronous calls one after another. */
+typedef struct hw_pipe hw_pipe;
+int  hw_pipe_create(const hw_params* p, int device, int32_t n_queues /* 1..4 */, hw_pipe** out);
+void hw_pipe_destroy(hw_pipe* pipe);
+int  hw_pipe_set_market(hw_pipe* pipe, const float* P, const float* f, int32_t n_mat);
+/* best_ms_per_call (may be NULL): time per call of the chosen streams over `launches` alternating calls of `sample`. */
+int  hw_pipe_tune(hw_pipe* pipe, const hw_zbc_request* sample, int32_t launches /* 0 = 16 */, float* best_ms_per_call);
+int  hw_pipe_zbc_moments(hw_pipe* pipe, const hw_zbc_request* reqs, int32_t n, double* out /* [n][5] */, float* wall_ms);
 
 /* ---- several GPUs in one process ---------------------------------------------------------------
  * (not in the reference, which is single-GPU).  A communicator spans contexts created on DIFFERENT

@@ -91,6 +91,11 @@ SIGNATURES = {
     "hw_comm_zcb_curve": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_double, _DP, C.POINTER(C.c_float)]),
     "hw_comm_vega_pathwise": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_double, C.c_double,
                                         C.c_int32, _DP, C.POINTER(C.c_float)]),
+    "hw_pipe_create": (C.c_int, [C.POINTER(HwParams), C.c_int, C.c_int32, C.POINTER(C.c_void_p)]),
+    "hw_pipe_destroy": (None, [C.c_void_p]),
+    "hw_pipe_set_market": (C.c_int, [C.c_void_p, _FP, _FP, C.c_int32]),
+    "hw_pipe_tune": (C.c_int, [C.c_void_p, C.POINTER(HwZbcRequest), C.c_int32, C.POINTER(C.c_float)]),
+    "hw_pipe_zbc_moments": (C.c_int, [C.c_void_p, C.POINTER(HwZbcRequest), C.c_int32, _DP, C.POINTER(C.c_float)]),
     "hw_drift_tables": (C.c_int, [_CTX, C.c_double, C.c_int32, _DP, _DP]),
     "hw_average_and_forward": (C.c_int, [C.POINTER(HwParams), _DP, C.c_int64, _FP, _FP]),
     "hw_recover_theta": (C.c_int, [C.POINTER(HwParams), _FP, _FP, _FP, _FP]),
@@ -121,7 +126,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
-    if lib.hw_abi_version() != 2:
+    if lib.hw_abi_version() != 3:
         raise ImportError("libhw_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -338,6 +338,66 @@ class HullWhiteEngine:
         return out.reshape(n_blocks, 4)
 
 
+class HullWhitePipeline:
+    """hw_pipe_*: a stream of independent pricing calls on one GPU with `queues` launches in flight (include/hw_mc.h).
+    Every request is one full pricing call; the sums equal those of separate HullWhiteEngine calls bit for bit."""
+
+    def __init__(self, params=None, device=0, queues=2, **kw):
+        self.lib = L.load()
+        self.params = params if params is not None else default_params(**kw)
+        self._pipe = C.c_void_p()
+        L.check(self.lib.hw_pipe_create(C.byref(self.params), int(device), int(queues), C.byref(self._pipe)))
+
+    def close(self):
+        if getattr(self, "_pipe", None):
+            self.lib.hw_pipe_destroy(self._pipe)
+            self._pipe = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def load_market_data(self, P, f):
+        P = np.ascontiguousarray(P, np.float32)
+        f = np.ascontiguousarray(f, np.float32)
+        L.check(self.lib.hw_pipe_set_market(self._pipe, _fp(P), _fp(f), len(P)))
+
+    @staticmethod
+    def _requests(n_pairs, seeds, path_offset, S1, S2, K, sigma, drift_mode, stepper):
+        reqs = (L.HwZbcRequest * len(seeds))()
+        for r, seed in zip(reqs, seeds):
+            r.n_pairs, r.seed, r.path_offset = int(n_pairs), int(seed), int(path_offset)
+            r.S1, r.S2, r.K = float(S1), float(S2), float(K_DEFAULT if K is None else K)
+            r.sigma, r.drift_mode, r.stepper = float(sigma), int(drift_mode), int(stepper)
+        return reqs
+
+    def tune(self, n_pairs, seed=1, launches=0, **kw):
+        """Pick the streams on this workload (untimed by callers); returns the best time per call in ms."""
+        reqs = self._requests(n_pairs, [seed], kw.get("path_offset", 0), kw.get("S1", 5.0), kw.get("S2", 10.0), kw.get("K"),
+                              kw.get("sigma", 0.0), kw.get("drift_mode", L.HW_DRIFT_BASE), kw.get("stepper", L.HW_STEPPER_SUPERPOSED))
+        ms = C.c_float(0)
+        L.check(self.lib.hw_pipe_tune(self._pipe, reqs, int(launches), C.byref(ms)))
+        return ms.value
+
+    def simulate_ZBC_batch(self, n_pairs, seeds, path_offset=0, S1=5.0, S2=10.0, K=None, sigma=0.0,
+                           drift_mode=L.HW_DRIFT_BASE, stepper=L.HW_STEPPER_SUPERPOSED, return_ms=False):
+        """One pricing call per seed, alternating over the queues -> float64[len(seeds), 5] (and the wall time in ms)."""
+        seeds = list(seeds)
+        reqs = self._requests(n_pairs, seeds, path_offset, S1, S2, K, sigma, drift_mode, stepper)
+        out = np.zeros((len(seeds), 5), np.float64)
+        ms = C.c_float(0)
+        L.check(self.lib.hw_pipe_zbc_moments(self._pipe, reqs, len(seeds), _dp(out), C.byref(ms)))
+        return (out, ms.value) if return_ms else out
+
+
 class HullWhiteFleet:
     """Several engines (one per device) in ONE process behind an RCCL communicator: every call shards the
     paths by global id, launches all devices asynchronously and sums with one grouped ncclAllReduce

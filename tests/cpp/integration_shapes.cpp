@@ -30,6 +30,13 @@ int main() {
     hw_comm_zbc_moments_runs(comm, &rq, 20, 12345ull, sums20, &wall_ms);          // the 20-run validation over the fleet
     hw_comm_destroy(comm);
     hw_comm_create_ex(1, ctxs, HW_COMM_HOST_SUM, &comm); hw_comm_destroy(comm);   // without RCCL
+    hw_pipe* pipe;  hw_pipe_create(&p, -1, /*n_queues*/ 2, &pipe);
+    hw_pipe_set_market(pipe, h_P, h_f, N_MAT);
+    hw_zbc_request rqs[20];
+    for (int k = 0; k < 20; k++) { rqs[k] = rq; rqs[k].seed = rq.seed + 12345ull * k; }
+    hw_pipe_tune(pipe, &rqs[0], 0, NULL);
+    hw_pipe_zbc_moments(pipe, rqs, 20, sums20, &wall_ms);
+    hw_pipe_destroy(pipe);
     hw_destroy(ctx);
     return 0;
 }
