@@ -48,6 +48,14 @@ benchmark: $(SRC)/benchmark_reductions.hip $(LIB)
 	@mkdir -p $(BIN) data plots
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I include $< -o $(BIN)/$@ $(LDFLAGS)
 
+# the headline metric from plain C++ over the C ABI (no Python, no torch): synchronous calls against hw_pipe_*
+throughput: $(SRC)/throughput.cpp $(LIB)
+	@mkdir -p $(BIN)
+	$(CXX) $(CXXFLAGS) $< -o $(BIN)/$@ $(LDFLAGS)
+
+run-throughput: throughput
+	./$(BIN)/throughput $(ARGS)
+
 run-benchmark: benchmark
 	@mkdir -p data plots
 	./$(BIN)/benchmark $(ARGS)
