@@ -701,7 +701,8 @@ int hw_get_device_info(hw_ctx* c, hw_device_info* out)
 {
     if (!c || !out) return fail(HW_E_INVALID, "null argument");
     memset(out, 0, sizeof *out);
-    snprintf(out->name, sizeof out->name, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+    // (the marketing name comes from libdrm's amdgpu.ids, which some images lack: the architecture string always exists)
+    snprintf(out->name, sizeof out->name, "%s (%s)", c->prop.name[0] ? c->prop.name : "AMD GPU", c->prop.gcnArchName);
     out->device = c->device;
     out->compute_units = c->prop.multiProcessorCount;
     out->clock_mhz = c->prop.clockRate / 1000;
