@@ -205,7 +205,14 @@ def main():
         if rehearsal:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            # HWMC_BENCH_RCCL_PRIORITY=high: torch's RCCL stream is created with high priority, so the tiny all-reduce
+            # kernels are dispatched ahead of the path kernels' pending workgroups (A/B switch)
+            if os.environ.get("HWMC_BENCH_RCCL_PRIORITY", "normal") == "high":
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+                dist.init_process_group("nccl", device_id=dev, pg_options=opts)
+            else:
+                dist.init_process_group("nccl", device_id=dev)
     cdev = "cpu" if rehearsal else dev                 # where the small control tensors of the collectives live
 
     import numpy as np
