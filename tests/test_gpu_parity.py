@@ -769,7 +769,7 @@ def test_single_launch_ticket_finish(setup, hwmc_mod, monkeypatch):
     t = hwmc_mod.HullWhiteEngine(p, device=0)
     monkeypatch.delenv("HWMC_SINGLE_LAUNCH")
     t.load_market_data(P, f)
-    for n in (1, 200, 256 * 7, 256 * 8 + 3, 100_000, (1 << 20) + 77):            # 1, 1, 7, 9, 391, 2049 workgroups
+    for n in (1, 200, 256 * 7, 256 * 8 + 3, 100_000, (1 << 20) + 77):            # 1, 1, 7, 9, 391, 1025 workgroups (the last: two pairs per thread)
         a = t.simulate_ZBC_control_variate(n, 31)
         np.testing.assert_allclose(a, e.simulate_ZBC_control_variate(n, 31), rtol=1e-13)
         assert np.array_equal(a, t.simulate_ZBC_control_variate(n, 31))             # tickets re-armed, fixed order
