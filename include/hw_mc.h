@@ -222,9 +222,9 @@ int  hw_get_kernel_info(hw_ctx* ctx, const char* kernel /* "zbc" | "zbc_ref" | "
  * queues in a way that depends on the process's history, and two streams that share a queue serialise, so hw_pipe_tune
  * times every pair of candidates on the caller's own workload and keeps the fastest (hw_pipe_zbc_moments tunes on its
  * first request if the caller has not).  hw_pipe_zbc_moments enqueues the n requests alternating over the queues -- every
- * request is one full pricing call, exactly hw_zbc_moments_async -- brings the n x 5 sums back with ONE copy and
- * synchronises once; the sums equal those of n separate hw_zbc_moments calls bit for bit.  wall_ms: host wall time of the
- * call.  Measured at 2^20 pairs x 500 steps: ~0.174 ms per call against 0.190 ms for synchronous calls one after another.
+ * request is one full pricing call, exactly hw_zbc_moments_async, whose column pass stores its five sums straight into
+ * pinned host memory -- and synchronises once; the sums equal those of n separate hw_zbc_moments calls bit for bit.  wall_ms: host wall time of the
+ * call.  Measured at 2^20 pairs x 500 steps: 0.172 ms per call against 0.201 ms for synchronous hw_zbc_moments calls one after another.
  * Like a context, a pipe is used by one host thread at a time; a request the engine refuses fails the whole batch before
  * anything is enqueued (HIP errors surfacing later leave nothing in flight either: the call synchronises the device). */
 typedef struct hw_pipe hw_pipe;

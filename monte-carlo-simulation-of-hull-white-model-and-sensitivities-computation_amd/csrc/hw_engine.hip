@@ -80,6 +80,11 @@ struct hw_ctx {
     double* d_partials = nullptr;
     size_t partials_cap = 0;          // doubles
     double* d_out = nullptr;          // result staging, kOutCap doubles
+    // The same in pinned, device-visible HOST memory: the synchronous entry points let the column pass store its few
+    // doubles straight to the host (posted PCIe writes, visible after the stream synchronisation) instead of running a
+    // device->host copy behind it (a blit kernel of its own: ~4 us + a launch gap per call, rocprofv3 of bin/q2).
+    double* h_out = nullptr;          // host address
+    double* h_out_dev = nullptr;      // the address the device uses for it
     double* d_scale = nullptr;        // per-column scale for the curve (n_mat doubles)
     float* d_drift = nullptr;         // float table for the reference stepper / sample paths
     unsigned* d_ticket = nullptr;     // grid_sum_finish ticket counter (self re-arming)
@@ -574,11 +579,11 @@ int timed_sync(hw_ctx* c, int n_out, double* out, float* kernel_ms, F enqueue)
     if (n_out > kOutCap) return fail(HW_E_INVALID, "too many outputs");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    int rc = enqueue(c->d_out, c->stream);
+    int rc = enqueue(c->h_out_dev, c->stream);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(hipMemcpyAsync(out, c->d_out, n_out * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_out, n_out * sizeof(double));
     free_retired(c);       // the context's stream has waited for every earlier launch of the context (use_stream)
     if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, c->ev0, c->ev1));
     return HW_OK;
@@ -652,6 +657,8 @@ int hw_create(const hw_params* p, int device, hw_ctx** out)
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_switch, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&c->d_out, kOutCap * sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_out, kOutCap * sizeof(double), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c->h_out_dev, c->h_out, 0);
     if (e == hipSuccess) e = hipMalloc(&c->d_scale, (size_t)p->n_mat * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&c->d_drift, (size_t)p->n_steps * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->d_clk, 64);
@@ -686,6 +693,7 @@ void hw_destroy(hw_ctx* c)
     if (c->ev_switch) (void)hipEventDestroy(c->ev_switch);
     if (c->d_partials) (void)hipFree(c->d_partials);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->d_scale) (void)hipFree(c->d_scale);
     if (c->d_drift) (void)hipFree(c->d_drift);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
@@ -1194,7 +1202,8 @@ struct hw_pipe {
     std::vector<hipStream_t> cand;       // candidate streams; chosen[q] indexes the one queue q uses
     std::vector<int> chosen;
     std::vector<hipEvent_t> ev;          // per queue: "everything enqueued on this queue so far"
-    double* d_out = nullptr;
+    double* h_out = nullptr;             // result rows in pinned, device-visible host memory: every column pass stores its five
+    double* h_out_dev = nullptr;         // sums straight to the host, no copy behind the batch
     size_t out_cap = 0;                  // doubles
     bool tuned = false;
 };
@@ -1207,10 +1216,11 @@ int pipe_ensure_out(hw_pipe* pp, size_t doubles)
 {
     if (doubles <= pp->out_cap) return HW_OK;
     HIP_TRY(hipDeviceSynchronize());                       // (only ever grows between calls: nothing is in flight)
-    if (pp->d_out) HIP_TRY(hipFree(pp->d_out));
-    pp->d_out = nullptr;
+    if (pp->h_out) HIP_TRY(hipHostFree(pp->h_out));
+    pp->h_out = pp->h_out_dev = nullptr;
     pp->out_cap = 0;
-    HIP_TRY(hipMalloc(&pp->d_out, doubles * sizeof(double)));
+    HIP_TRY(hipHostMalloc((void**)&pp->h_out, doubles * sizeof(double), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void**)&pp->h_out_dev, pp->h_out, 0));
     pp->out_cap = doubles;
     return HW_OK;
 }
@@ -1221,19 +1231,19 @@ int pipe_run(hw_pipe* pp, const std::vector<int>& use, const hw_zbc_request* req
     const int Q = (int)use.size();
     for (int i = 0; i < n; i++) {
         const int q = i % Q;
-        const int rc = zbc_enqueue(pp->ctx[q], same_request ? reqs : reqs + i, 1, nullptr, nullptr, pp->d_out + (size_t)5 * i, pp->cand[use[q]]);
+        const int rc = zbc_enqueue(pp->ctx[q], same_request ? reqs : reqs + i, 1, nullptr, nullptr, pp->h_out_dev + (size_t)5 * i, pp->cand[use[q]]);
         if (rc) {
             (void)hipDeviceSynchronize();                  // leave nothing in flight behind an error
             return rc;
         }
     }
     hipStream_t s0 = pp->cand[use[0]];
-    for (int q = 1; q < Q && q < n; q++) {                 // queue 0 waits for the others, then carries the copy
+    for (int q = 1; q < Q && q < n; q++) {                 // queue 0 waits for the others: ONE host synchronisation
         HIP_TRY(hipEventRecord(pp->ev[q], pp->cand[use[q]]));
         HIP_TRY(hipStreamWaitEvent(s0, pp->ev[q], 0));
     }
-    if (host_out && n > 0) HIP_TRY(hipMemcpyAsync(host_out, pp->d_out, (size_t)5 * n * sizeof(double), hipMemcpyDeviceToHost, s0));
     HIP_TRY(hipStreamSynchronize(s0));
+    if (host_out && n > 0) memcpy(host_out, pp->h_out, (size_t)5 * n * sizeof(double));
     for (hw_ctx* c : pp->ctx) free_retired(c);
     return HW_OK;
 }
@@ -1285,7 +1295,7 @@ void hw_pipe_destroy(hw_pipe* pp)
     for (hw_ctx* c : pp->ctx) hw_destroy(c);               // (before the streams: a context may still name one as its last)
     for (hipEvent_t ev : pp->ev) (void)hipEventDestroy(ev);
     for (hipStream_t st : pp->cand) (void)hipStreamDestroy(st);
-    if (pp->d_out) (void)hipFree(pp->d_out);
+    if (pp->h_out) (void)hipHostFree(pp->h_out);
     delete pp;
 }
 
@@ -1507,10 +1517,11 @@ static int comm_run(hw_comm* cm, int64_t n_units, int count_out, double* out, fl
         hw_ctx* c = cm->ctx[g];
         int64_t off, cnt;
         comm_shard(n_units, g, G, &off, &cnt);
-        int rc = enqueue(g, off, cnt, c->d_out, c->stream);
+        int rc = enqueue(g, off, cnt, cm->host_sum ? c->h_out_dev : c->d_out, c->stream);
         if (rc) return rc;
         if (cm->host_sum) {
-            HIP_TRY(hipMemcpyAsync(&cm->host_slots[(size_t)g * kOutCap], c->d_out, count_out * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));          // the column pass stored the sums straight to pinned host memory
+            memcpy(&cm->host_slots[(size_t)g * kOutCap], c->h_out, count_out * sizeof(double));
         } else {
             // one communicator per thread: no group call needed (each rank's call comes from its own thread, as in the
             // one-process-per-GPU layout)
