@@ -28,6 +28,11 @@ Pipelining.  The K steps are independent pricing batches, so each GPU alternates
 the last waves are covered by the next batch.  Every batch is still one full launch; the sums are bit-identical to the
 single-stream run, and the line carries the strictly serial rate ("serial") and the kernel alone on the chip
 ("kernel_Mpaths_per_sec_isolated_launch", which is what rocprofv3 --stats reports for --streams 1) next to `value`.
+
+Side measurements in the same line (untimed, N = 1; --no-extras drops them): `long_region` (10 K steps between two
+synchronisations: what starting and draining the pipeline once per K steps costs), `library_pipeline` (the same K calls
+through the C ABI's own hw_pipe_zbc_moments: one function call, no torch), `other_stepper`, `runs20_single_launch`,
+`q1_curve_gpu`, `strong_scaling_reference`; `cpu_baseline` = the oracle on the host cores (the only use of oracle/ here).
 """
 import argparse
 import glob
