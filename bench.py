@@ -24,8 +24,8 @@ region is repeated --regions times (fresh barriers each time) and `value` is the
 it: at 2^20 pairs a region lasts only K * 0.18 ms.
 
 Pipelining.  The K steps are independent pricing batches, so each GPU alternates them over S contexts (S HIP streams,
---streams, default 2): the ~13 us a launch spends outside the kernel (dispatch, end-of-kernel release) and the drain of
-the last waves are covered by the next batch.  Every batch is still one full launch; the sums are bit-identical to the
+--streams, default 2): the drain of a launch's last waves (~11 us at 2^20 pairs) and the ~4 us it spends outside its waves
+(dispatch, end-of-kernel release) are covered by the next batch.  Every batch is still one full launch; the sums are bit-identical to the
 single-stream run, and the line carries the strictly serial rate ("serial") and the kernel alone on the chip
 ("kernel_Mpaths_per_sec_isolated_launch", which is what rocprofv3 --stats reports for --streams 1) next to `value`.
 

@@ -216,8 +216,8 @@ int  hw_get_kernel_info(hw_ctx* ctx, const char* kernel /* "zbc" | "zbc_ref" | "
 
 /* ---- a stream of independent pricing calls on ONE GPU, two queues in flight -------------------------
  * (not in the reference: its 20-run validation launches, synchronises and copies 20 times, src/2_option_pricing.cu:225-302).
- * A launch of 2^20 pairs spends ~11 us of its ~187 us outside its kernel (dispatch, end-of-kernel release) and drains
- * through a last round of half-empty CUs; a second launch in flight on another hardware queue fills both.  A pipe owns
+ * A launch of 2^20 pairs spends ~4 us of its ~187 us outside its waves (dispatch, end-of-kernel release) and ~11 us
+ * draining through a thinning last round of waves; a second launch in flight on another hardware queue fills both.  A pipe owns
  * n_queues contexts (each with its own workspaces) and a set of candidate streams; HIP maps streams onto a few hardware
  * queues in a way that depends on the process's history, and two streams that share a queue serialise, so hw_pipe_tune
  * times every pair of candidates on the caller's own workload and keeps the fastest (hw_pipe_zbc_moments tunes on its

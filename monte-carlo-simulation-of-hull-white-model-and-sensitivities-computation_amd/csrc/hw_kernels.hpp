@@ -1073,8 +1073,10 @@ zbc_superposed_kernel(const ZbcArgs<REAL, NSCEN> a, double* __restrict__ partial
         a.clk[2] = __builtin_amdgcn_s_memtime();
         a.clk[3] = __builtin_amdgcn_s_memrealtime();
     }
-    wg_stamp.end(a.stamps);      // (before the cross-wave finish: the stamp is the end of this workgroup's path work)
     grid_sum_finish<5 * NSCEN>(acc, smem, partials, ticket, out);
+    // after the cross-wave finish (its barrier): the end of the workgroup's LAST wave.  (Stamped before it, thread 0 reports
+    // when wave 0 -- the oldest of the workgroup, which the issue arbiter favours -- finished its paths: up to ~10 us early.)
+    wg_stamp.end(a.stamps);
 }
 
 // ------------------------------------------------------------------------------------------
