@@ -65,10 +65,12 @@ def test_bench_flag_combinations(args, env):
 
 def test_bench_default_line_carries_the_side_measurements():
     """No flags beyond a short K: the N = 1 line must hold the other stepper, the 20-run single launch, the Q1 curve kernel
-    at configs[0]'s size and the 2^24-pair strong-scaling reference, all as throughputs in the metric's unit."""
+    at configs[0]'s size, the 2^24-pair strong-scaling reference, the 10 K-step region and the same K calls through the
+    library's own pipe (whose sums bench.py itself compares with the timed region's), all as throughputs in the metric's unit."""
     d = _bench("--steps", "6", "--regions", "3")
-    for key in ("other_stepper", "runs20_single_launch", "q1_curve_gpu", "strong_scaling_reference", "serial"):
+    for key in ("other_stepper", "runs20_single_launch", "q1_curve_gpu", "strong_scaling_reference", "serial", "long_region", "library_pipeline"):
         assert d[key]["value"] > 0, key
+    assert d["long_region"]["steps"] == 60 and d["library_pipeline"]["api"] == "hw_pipe_zbc_moments" and d["library_pipeline"]["steps"] == 6
     assert d["strong_scaling_reference"]["pairs_per_step"] == 1 << 24 and d["config"]["pairs_per_step"] == 1 << 20
     assert d["scaling"] == "strong" and d["config"]["effective_paths"] == 2 << 20
     assert d["runs20_single_launch"]["value"] > 0.9 * d["serial"]["value"]
