@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HW_ABI_VERSION 3   /* 3: + hw_pipe_* (additive) */
+#define HW_ABI_VERSION 4   /* 4: + hw_debug_exp2 (additive); stream-lifetime rule of the *_async calls stated */
 
 /* error codes */
 #define HW_OK            0
@@ -40,7 +40,12 @@ extern "C" {
 #define HW_E_NO_MARKET  -3   /* hw_set_market not called ("Did you run Q1 first?") */
 #define HW_E_NOMEM      -4
 
-/* precision of the per-path stepper and payoff arithmetic */
+/* precision of the per-path stepper and payoff arithmetic.
+ * HW_F64 = double STATE and ACCUMULATION with float transcendentals: the normals are float32 Box-Muller values (as in
+ * the reference, curand_normal is float) and every exp2 of a discount factor / bond price goes through v_exp_f32 on
+ * the float-rounded argument plus a first-order correction (measured: max 8.4e-8 relative, sd 2.6e-8, mean signed error -2.3e-9; bounds pinned by
+ * tests/test_gpu_parity.py::test_device_exp2_of_a_double).  It answers "what does float STEPPING cost in accuracy"
+ * (BASELINE configs[4]); it is not a correctly-rounded double reference -- the CPU oracle in double is. */
 #define HW_F32 0
 #define HW_F64 1
 
@@ -120,7 +125,8 @@ int  hw_set_market(hw_ctx* ctx, const float* P, const float* f, int32_t n_mat);
  * grid cap in workgroups per CU (0 = none: one thread slot per pair, the dispatcher hands the workgroups out;
  * with a cap the threads loop), drift-table staging for the REFERENCE stepper (0 scalar loads, 1 LDS), pairs in
  * flight per thread (1 or 2; 0 keeps the current choice, -1 returns to automatic: 2 -- their Philox blocks
- * interleaved -- from four chip-fills of pairs up in the float engine when a path has at most 1024 steps, else 1).  Environment, read by hw_create: HWMC_SINGLE_LAUNCH=1 finishes the grid-wide sums
+ * interleaved -- from TWO chip-fills of pairs up (2^20 on 256 CUs; the Vega kernel: four) in the float engine when a
+ * path has at most 1024 steps, else 1).  Environment, read by hw_create: HWMC_SINGLE_LAUNCH=1 finishes the grid-wide sums
  * inside the path kernel (sharded tickets) instead of a second launch; HWMC_CURVE_GENERIC=1 always runs the per-step
  * curve kernel.  None of them changes a result beyond the last bits of the double sums. */
 int  hw_set_launch(hw_ctx* ctx, int32_t block_size, int32_t max_blocks_per_cu, int32_t table_in_lds,
@@ -137,7 +143,14 @@ int  hw_zbc_moments(hw_ctx* ctx, const hw_zbc_request* req, double out[5], float
  * (partial sums, tables), in stream order.  Calls on ONE stream pipeline freely.  A call on a different stream
  * than the context's previous call is still correct: its stream is first made to wait, on the device, for
  * everything the context has enqueued before (an event, no host wait) -- so two streams never overlap through
- * one context.  For overlap use one context per stream (bench.py does).  Host blocking: none in the steady
+ * one context.  For overlap use one context per stream (bench.py does).
+ * Stream lifetime.  A stream passed to an *_async call must be alive for the duration of THAT CALL, nothing more: the
+ * library never touches a caller's stream handle after the call that received it has returned.  (What a later call
+ * on another stream, or hw_destroy, waits for is an event of the context, recorded on the caller's stream at the end
+ * of the call that used it: one hipEventRecord per *_async call on a caller's stream, none on the context's own
+ * stream.)  The caller may therefore synchronise and destroy its stream at any time after the call, before or after
+ * hw_destroy.  Destroying a stream that still has work of the context in flight is the caller's business, as with
+ * any HIP work: hipStreamDestroy lets that work finish.  Host blocking: none in the steady
  * state; the call may block the HOST only when it has to grow the workspace (hipMalloc, first call at a larger
  * size -- the outgrown buffer is released later, never under running kernels) or when four table uploads of
  * this context are still in flight (pinned staging ring). */
@@ -192,6 +205,10 @@ int  hw_debug_normals(hw_ctx* ctx, uint64_t seed, uint64_t subseq, int32_t n_blo
 /* Same blocks as raw 32-bit Philox words (out[n_blocks*4]), bit-exact against rocrand4(). */
 int  hw_debug_raw(hw_ctx* ctx, uint64_t seed, uint64_t subseq, int32_t n_blocks, uint32_t* out);
 
+/* out[i] = the double engine's exp2(x[i]) evaluated ON THE GPU (v_exp_f32 of the float-rounded argument + first-order
+ * correction, see HW_F64): lets a test pin its error against libm. */
+int  hw_debug_exp2(hw_ctx* ctx, const double* x, int32_t n, double* out);
+
 /* Per-launch kernel timing for benchmarks: after hw_profile_enable(ctx, n) each *_async / sync
  * hot-path call records a hipEvent pair on its launch stream tightly around the PATH kernel
  * (not the column reduction), for up to n launches.  hw_profile_read synchronises those events
@@ -226,7 +243,9 @@ int  hw_get_kernel_info(hw_ctx* ctx, const char* kernel /* "zbc" | "zbc_ref" | "
  * pinned host memory -- and synchronises once; the sums equal those of n separate hw_zbc_moments calls bit for bit.  wall_ms: host wall time of the
  * call.  Measured at 2^20 pairs x 500 steps: 0.172 ms per call against 0.201 ms for synchronous hw_zbc_moments calls one after another.
  * Like a context, a pipe is used by one host thread at a time; a request the engine refuses fails the whole batch before
- * anything is enqueued (HIP errors surfacing later leave nothing in flight either: the call synchronises the device). */
+ * anything is enqueued (HIP errors surfacing later leave nothing in flight either: the call synchronises the device).
+ * hw_pipe_zbc_moments on an untuned pipe tunes first on a copy of reqs[0] capped at 2^20 pairs, 8 launches per trial
+ * (~0.1 s once, not part of wall_ms); call hw_pipe_tune yourself to keep that out of the first pricing call. */
 typedef struct hw_pipe hw_pipe;
 int  hw_pipe_create(const hw_params* p, int device, int32_t n_queues /* 1..4 */, hw_pipe** out);
 void hw_pipe_destroy(hw_pipe* pipe);
@@ -241,9 +260,15 @@ int  hw_pipe_zbc_moments(hw_pipe* pipe, const hw_zbc_request* reqs, int32_t n, d
  * (context g gets a contiguous block); one persistent host thread per device (started by hw_comm_create)
  * enqueues that device's shard and ONE ncclAllReduce on the device's stream (RCCL over xGMI; librccl.so.1 is
  * loaded at hw_comm_create, the library itself does not link it) and waits for it.  wall_ms: host wall time from the first launch to the reduced result.
- * Errors: a request is checked against EVERY context on the calling thread before any device is given work (a device
- * that refused its shard would leave the others waiting in the all-reduce); failures found by a worker afterwards
- * (HIP / RCCL errors, launch geometry) come back as "device <id>: <text>" through hw_last_error(). */
+ * Errors: a request is checked against EVERY context on the calling thread before any device is given work.  What
+ * only one device can find out at run time (workspace growth, table upload, launch geometry, a launch error) is caught
+ * by a two-phase job: every worker first enqueues its shard's kernels, the workers meet, and the all-reduce is entered
+ * only if ALL of them succeeded -- otherwise nobody enters it, every device drains, the call returns "device <id>:
+ * <text>" of the failing rank through hw_last_error() and the communicator stays usable.  A failure after that point
+ * (inside the collective or the synchronisation behind it) aborts every communicator (ncclCommAbort, which releases
+ * ranks blocked in the collective): the call returns the error and every later call on this hw_comm is refused;
+ * destroy it and create a new one.  HWMC_COMM_INJECT_FAIL=rank:phase[:count] (read by hw_comm_create*) makes rank
+ * `rank` fail in phase 1 or 2 of its next `count` jobs: the rehearsal tests' switch, not for production. */
 typedef struct hw_comm hw_comm;
 int  hw_comm_create(int32_t n, hw_ctx* const* ctxs, hw_comm** out);
 /* The same with a choice of how the shards' sums are combined: HW_COMM_RCCL (what hw_comm_create does) or

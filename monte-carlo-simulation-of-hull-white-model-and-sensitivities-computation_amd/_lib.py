@@ -76,6 +76,7 @@ SIGNATURES = {
     "hw_sample_paths": (C.c_int, [_CTX, C.c_int32, C.c_uint64, C.c_uint64, _FP]),
     "hw_debug_normals": (C.c_int, [_CTX, C.c_uint64, C.c_uint64, C.c_int32, _FP]),
     "hw_debug_raw": (C.c_int, [_CTX, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_uint32)]),
+    "hw_debug_exp2": (C.c_int, [_CTX, _DP, C.c_int32, _DP]),
     "hw_profile_enable": (C.c_int, [_CTX, C.c_int32]),
     "hw_profile_read": (C.c_int, [_CTX, _FP, C.c_int32, C.POINTER(C.c_int32)]),
     "hw_profile_clock": (C.c_int, [_CTX, _DP]),
@@ -126,7 +127,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
-    if lib.hw_abi_version() != 3:
+    if lib.hw_abi_version() != 4:
         raise ImportError("libhw_hip.so ABI version mismatch")
     _lib = lib
     return lib

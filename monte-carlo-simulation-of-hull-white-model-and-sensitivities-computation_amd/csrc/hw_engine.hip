@@ -106,10 +106,17 @@ struct hw_ctx {
     int prof_used = 0, prof_cap = 0;
     // The workspaces above are reused by every launch of the context, in stream order.  A call that arrives on a
     // DIFFERENT stream than the previous one first makes its stream wait (on the device) for everything the context
-    // has enqueued so far: use_stream().
-    hipStream_t last_stream = nullptr;
-    bool have_last_stream = false;
-    hipEvent_t ev_switch = nullptr;
+    // has enqueued so far: on_stream().  RULE: the library never hands a caller's stream handle to HIP after the call
+    // that received it has returned (the caller may destroy the stream any time after that).  So `tail_stream` is
+    // only ever COMPARED; what the next call waits on is `ev_tail`, an event of the context, recorded on a caller's
+    // stream at the END of the call that used it (seal_stream), while the stream is certainly alive.  For streams the
+    // library owns itself -- the context's own, a pipe's candidates -- the record is deferred to the moment another
+    // stream actually shows up (use_stream): calls that stay on one owned stream pay nothing.
+    hipStream_t tail_stream = nullptr;    // stream of the context's latest enqueue: a VALUE to compare, not a handle to use
+    bool have_tail = false;
+    bool tail_recorded = false;           // ev_tail covers everything this context has enqueued so far
+    hipEvent_t ev_tail = nullptr;
+    bool streams_owned = false;           // hw_pipe: every stream it passes in is the pipe's own and outlives the context
     // workspaces outgrown while launches may still be reading them: freed at the next host synchronisation / destroy
     std::vector<void*> retired;
     // pinned staging ring for the small host->device uploads (drift table of the REFERENCE stepper, per-maturity
@@ -148,17 +155,43 @@ void free_retired(hw_ctx* c)          // caller guarantees that nothing enqueued
 }
 
 // Stream-order guard of the per-context workspaces (d_partials, d_ticket, d_drift, d_scale): see hw_ctx.
+inline bool stream_is_owned(const hw_ctx* c, hipStream_t st) { return st == c->stream || c->streams_owned; }
+
 int use_stream(hw_ctx* c, hipStream_t st)
 {
-    if (c->have_last_stream && c->last_stream != st) {
-        // everything enqueued so far on the old stream.  If the caller has destroyed that stream in the meantime the record
-        // fails; hipStreamDestroy completes a stream's work first, so there is nothing left to wait for.
-        if (hipEventRecord(c->ev_switch, c->last_stream) == hipSuccess) HIP_TRY(hipStreamWaitEvent(st, c->ev_switch, 0));
-        else (void)hipGetLastError();
+    if (c->have_tail && c->tail_stream != st) {
+        if (!c->tail_recorded) {
+            // only reachable for a stream the library owns (seal_stream records every other one before its call returns)
+            if (!stream_is_owned(c, c->tail_stream)) return fail(HW_E_HIP, "internal: unsealed caller stream in the context's stream guard");
+            HIP_TRY(hipEventRecord(c->ev_tail, c->tail_stream));
+            c->tail_recorded = true;
+        }
+        HIP_TRY(hipStreamWaitEvent(st, c->ev_tail, 0));
     }
-    c->last_stream = st;
-    c->have_last_stream = true;
+    c->tail_recorded = false;             // new work is about to follow on st: ev_tail (if recorded) no longer covers it
+    c->tail_stream = st;
+    c->have_tail = true;
     return HW_OK;
+}
+
+// End of an enqueue on `st`: if it is a caller's stream, record the context's tail event on it NOW.
+int seal_stream(hw_ctx* c, hipStream_t st)
+{
+    if (!c->have_tail || c->tail_stream != st || c->tail_recorded || stream_is_owned(c, st)) return HW_OK;
+    HIP_TRY(hipEventRecord(c->ev_tail, st));
+    c->tail_recorded = true;
+    return HW_OK;
+}
+
+// Every enqueue of a context runs inside this bracket (whatever it returns, the stream is sealed).
+template <typename F>
+int on_stream(hw_ctx* c, hipStream_t st, F body)
+{
+    int rc = use_stream(c, st);
+    if (rc) return rc;
+    rc = body();
+    const int rs = seal_stream(c, st);
+    return rc ? rc : rs;
 }
 
 // Copy `bytes` from host memory to `dst` on stream `st` through the pinned ring: the caller's buffer may be a
@@ -321,9 +354,7 @@ int launch_zbc_superposed(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, co
     const Geometry g = geometry(c, r->n_pairs, ilp);
     if ((int64_t)g.grid * n_runs > ((int64_t)1 << 22)) return fail(HW_E_INVALID, "n_runs x workgroups per run exceeds 2^22");
     const int total_grid = g.grid * n_runs;
-    int rc = use_stream(c, st);
-    if (rc) return rc;
-    rc = ensure_partials(c, (size_t)total_grid * 5 * NSCEN);
+    int rc = ensure_partials(c, (size_t)total_grid * 5 * NSCEN);
     if (rc) return rc;
     hwk::ZbcArgs<REAL, NSCEN> a{};
     a.n_pairs = r->n_pairs;
@@ -351,9 +382,7 @@ int launch_zbc_reference(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, con
                          double* d_out, hipStream_t st)
 {
     const Geometry g = geometry(c, r->n_pairs, 1);
-    int rc = use_stream(c, st);
-    if (rc) return rc;
-    rc = ensure_partials(c, (size_t)g.grid * 5);
+    int rc = ensure_partials(c, (size_t)g.grid * 5);
     if (rc) return rc;
     if (!(c->drift_valid && c->drift_key_sigma == s.sigma && c->drift_key_mode == s.drift_mode && c->drift_key_n == n_steps_S1)) {
         std::vector<float> tab(n_steps_S1);
@@ -391,8 +420,8 @@ int launch_zbc_reference(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, con
     return finish_columns(c, st, g.grid, 5, d_out);
 }
 
-int zbc_enqueue(hw_ctx* c, const hw_zbc_request* r, int n_scen, const double* sigma,
-                const int32_t* drift_mode, double* d_out, hipStream_t st)
+int zbc_enqueue_body(hw_ctx* c, const hw_zbc_request* r, int n_scen, const double* sigma,
+                     const int32_t* drift_mode, double* d_out, hipStream_t st)
 {
     int n_steps_S1 = 0;
     int rc = check_request(c, r, &n_steps_S1);
@@ -421,6 +450,12 @@ int zbc_enqueue(hw_ctx* c, const hw_zbc_request* r, int n_scen, const double* si
     }
 }
 
+int zbc_enqueue(hw_ctx* c, const hw_zbc_request* r, int n_scen, const double* sigma,
+                const int32_t* drift_mode, double* d_out, hipStream_t st)
+{
+    return on_stream(c, st, [&] { return zbc_enqueue_body(c, r, n_scen, sigma, drift_mode, d_out, st); });
+}
+
 template <typename REAL>
 int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, double sigma,
                double* d_P_sum, hipStream_t st)
@@ -428,10 +463,6 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
     const hw_params& p = c->p;
     if (!(sigma > 0.0)) sigma = p.sigma;
     const int n_mat = p.n_mat, stride = p.n_steps / (n_mat - 1);
-    {
-        const int rcu = use_stream(c, st);
-        if (rcu) return rcu;
-    }
     const hw::StepConstants k = hw::step_constants(p, sigma);
     if (!(c->scale_valid && c->scale_key_sigma == sigma)) {
         std::vector<double> drift, m, cI;
@@ -539,8 +570,6 @@ int launch_vega(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset,
     const Geometry g = geometry(c, n_paths, ilp);
     if ((int64_t)g.grid * n_runs > ((int64_t)1 << 22)) return fail(HW_E_INVALID, "n_runs x workgroups per run exceeds 2^22");
     const int total_grid = g.grid * n_runs;
-    rc = use_stream(c, st);
-    if (rc) return rc;
     rc = ensure_partials(c, (size_t)total_grid);
     if (rc) return rc;
     hwk::VegaArgs<REAL> a{};
@@ -655,7 +684,7 @@ int hw_create(const hw_params* p, int device, hw_ctx** out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_switch, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&c->d_out, kOutCap * sizeof(double));
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_out, kOutCap * sizeof(double), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c->h_out_dev, c->h_out, 0);
@@ -684,13 +713,18 @@ void hw_destroy(hw_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->have_last_stream && c->last_stream != c->stream) (void)hipStreamSynchronize(c->last_stream);
+    // work the context left on another stream: wait on the context's OWN event (recorded when that call ended), never on
+    // the caller's stream handle, which may be gone; a pipe's streams are the library's and still alive here
+    if (c->have_tail && c->tail_stream != c->stream) {
+        if (c->tail_recorded) (void)hipEventSynchronize(c->ev_tail);
+        else if (c->streams_owned) (void)hipStreamSynchronize(c->tail_stream);
+    }
     free_retired(c);
     for (hw_ctx::Stage& sl : c->stage) {
         if (sl.h) (void)hipHostFree(sl.h);
         if (sl.ev) (void)hipEventDestroy(sl.ev);
     }
-    if (c->ev_switch) (void)hipEventDestroy(c->ev_switch);
+    if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
     if (c->d_partials) (void)hipFree(c->d_partials);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->h_out) (void)hipHostFree(c->h_out);
@@ -798,8 +832,10 @@ static int zbc_runs_enqueue(hw_ctx* c, const hw_zbc_request* r, int32_t n_runs, 
     Scenario sc;
     rc = build_scenario(c, r->sigma, r->drift_mode, n_steps_S1, r->S1, r->S2, &sc);
     if (rc) return rc;
-    return c->p.precision == HW_F64 ? launch_zbc_superposed<double, 1>(c, r, n_steps_S1, &sc, d_out, st, n_runs, seed_stride)
-                                    : launch_zbc_superposed<float, 1>(c, r, n_steps_S1, &sc, d_out, st, n_runs, seed_stride);
+    return on_stream(c, st, [&] {
+        return c->p.precision == HW_F64 ? launch_zbc_superposed<double, 1>(c, r, n_steps_S1, &sc, d_out, st, n_runs, seed_stride)
+                                        : launch_zbc_superposed<float, 1>(c, r, n_steps_S1, &sc, d_out, st, n_runs, seed_stride);
+    });
 }
 
 int hw_zbc_moments_runs(hw_ctx* c, const hw_zbc_request* r, int32_t n_runs, uint64_t seed_stride, double* out,
@@ -817,8 +853,10 @@ static int zcb_enqueue(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_
                        double* d_P_sum, hipStream_t st)
 {
     if (n_pairs < 0) return fail(HW_E_INVALID, "n_pairs < 0");
-    return c->p.precision == HW_F64 ? launch_zcb<double>(c, n_pairs, seed, path_offset, sigma, d_P_sum, st)
-                                    : launch_zcb<float>(c, n_pairs, seed, path_offset, sigma, d_P_sum, st);
+    return on_stream(c, st, [&] {
+        return c->p.precision == HW_F64 ? launch_zcb<double>(c, n_pairs, seed, path_offset, sigma, d_P_sum, st)
+                                        : launch_zcb<float>(c, n_pairs, seed, path_offset, sigma, d_P_sum, st);
+    });
 }
 
 int hw_zcb_curve(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, double sigma,
@@ -847,9 +885,11 @@ static int vega_enqueue(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path
     int n_steps_S1 = 0;
     int rc = check_request(c, &r, &n_steps_S1);
     if (rc) return rc;
-    return c->p.precision == HW_F64
-               ? launch_vega<double>(c, n_paths, seed, path_offset, S1, S2, K, antithetic, n_steps_S1, d_out, st)
-               : launch_vega<float>(c, n_paths, seed, path_offset, S1, S2, K, antithetic, n_steps_S1, d_out, st);
+    return on_stream(c, st, [&] {
+        return c->p.precision == HW_F64
+                   ? launch_vega<double>(c, n_paths, seed, path_offset, S1, S2, K, antithetic, n_steps_S1, d_out, st)
+                   : launch_vega<float>(c, n_paths, seed, path_offset, S1, S2, K, antithetic, n_steps_S1, d_out, st);
+    });
 }
 
 int hw_vega_pathwise(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset, double S1,
@@ -872,9 +912,11 @@ int hw_vega_pathwise_runs(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t pa
     int rc = check_request(c, &r, &n_steps_S1);
     if (rc) return rc;
     return timed_sync(c, n_runs, out, kernel_ms, [&](double* d_out, hipStream_t st) {
-        return c->p.precision == HW_F64
-                   ? launch_vega<double>(c, n_paths, seed, path_offset, S1, S2, K, antithetic, n_steps_S1, d_out, st, n_runs, seed_stride)
-                   : launch_vega<float>(c, n_paths, seed, path_offset, S1, S2, K, antithetic, n_steps_S1, d_out, st, n_runs, seed_stride);
+        return on_stream(c, st, [&] {
+            return c->p.precision == HW_F64
+                       ? launch_vega<double>(c, n_paths, seed, path_offset, S1, S2, K, antithetic, n_steps_S1, d_out, st, n_runs, seed_stride)
+                       : launch_vega<float>(c, n_paths, seed, path_offset, S1, S2, K, antithetic, n_steps_S1, d_out, st, n_runs, seed_stride);
+        });
     });
 }
 
@@ -972,6 +1014,27 @@ int hw_debug_raw(hw_ctx* c, uint64_t seed, uint64_t subseq, int32_t n_blocks, ui
     if (e != hipSuccess) return fail(HW_E_HIP, "hw_debug_raw: %s", hipGetErrorString(e));
     for (int j = 0; j < n_blocks; j++)
         for (int w = 0; w < 4; w++) out[4 * j + w] = raw[8 * j + w];
+    return HW_OK;
+}
+
+int hw_debug_exp2(hw_ctx* c, const double* x, int32_t n, double* out)
+{
+    if (!c || !x || !out) return fail(HW_E_INVALID, "null argument");
+    if (n < 1 || n > (1 << 24)) return fail(HW_E_INVALID, "n out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    double *d_x = nullptr, *d_o = nullptr;
+    HIP_TRY(hipMalloc(&d_x, (size_t)n * sizeof(double)));
+    hipError_t e = hipMalloc(&d_o, (size_t)n * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_x, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(hwk::debug_exp2_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const double*)d_x, d_o, n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_x);
+    if (d_o) (void)hipFree(d_o);
+    if (e != hipSuccess) return fail(HW_E_HIP, "hw_debug_exp2: %s", hipGetErrorString(e));
     return HW_OK;
 }
 
@@ -1238,11 +1301,16 @@ int pipe_run(hw_pipe* pp, const std::vector<int>& use, const hw_zbc_request* req
         }
     }
     hipStream_t s0 = pp->cand[use[0]];
-    for (int q = 1; q < Q && q < n; q++) {                 // queue 0 waits for the others: ONE host synchronisation
-        HIP_TRY(hipEventRecord(pp->ev[q], pp->cand[use[q]]));
-        HIP_TRY(hipStreamWaitEvent(s0, pp->ev[q], 0));
+    hipError_t e = hipSuccess;
+    for (int q = 1; q < Q && q < n && e == hipSuccess; q++) {   // queue 0 waits for the others: ONE host synchronisation
+        e = hipEventRecord(pp->ev[q], pp->cand[use[q]]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s0, pp->ev[q], 0);
     }
-    HIP_TRY(hipStreamSynchronize(s0));
+    if (e == hipSuccess) e = hipStreamSynchronize(s0);
+    if (e != hipSuccess) {
+        (void)hipDeviceSynchronize();                      // the header's promise: nothing in flight behind an error
+        return fail(HW_E_HIP, "hw_pipe: %s", hipGetErrorString(e));
+    }
     if (host_out && n > 0) memcpy(host_out, pp->h_out, (size_t)5 * n * sizeof(double));
     for (hw_ctx* c : pp->ctx) free_retired(c);
     return HW_OK;
@@ -1263,6 +1331,7 @@ int hw_pipe_create(const hw_params* p, int device, int32_t n_queues, hw_pipe** o
         hw_ctx* c = nullptr;
         const int rc = hw_create(p, q == 0 ? device : pp->device, &c);
         if (rc) { hw_pipe_destroy(pp); return rc; }
+        c->streams_owned = true;                          // the pipe's candidate streams are destroyed after its contexts
         pp->ctx.push_back(c);
         pp->device = c->device;                            // (device < 0: every queue on the device the first context picked)
     }
@@ -1391,7 +1460,12 @@ int hw_pipe_zbc_moments(hw_pipe* pp, const hw_zbc_request* reqs, int32_t n, doub
     }
     HIP_TRY(hipSetDevice(pp->device));
     if (!pp->tuned) {
-        const int rc = hw_pipe_tune(pp, reqs, 0, nullptr);
+        // automatic tuning on the first request: which streams share a hardware queue does not depend on the batch size,
+        // so the sample is capped at 2^20 pairs and 8 launches per trial (~0.1 s whatever the caller's request;
+        // hw_pipe_tune called by hand uses the request as given)
+        hw_zbc_request sample = reqs[0];
+        sample.n_pairs = std::min<int64_t>(sample.n_pairs, (int64_t)1 << 20);
+        const int rc = hw_pipe_tune(pp, &sample, 8, nullptr);
         if (rc) return rc;
     }
     int rc = pipe_ensure_out(pp, (size_t)5 * n);
@@ -1420,6 +1494,7 @@ struct hw_comm {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     // workers
     std::vector<std::thread> workers;
@@ -1436,13 +1511,18 @@ struct hw_comm {
     // on a box with one GPU.
     bool host_sum = false;
     std::vector<double> host_slots;        // [G][kOutCap]
+    // Two-phase job (comm_run): phase 1 = everything that can fail on ONE device (geometry, workspace growth, table
+    // upload, kernel launches), no collective; the workers then meet here and enter phase 2 (the all-reduce) only if
+    // EVERY rank got through phase 1 -- a rank that failed alone would leave the others waiting in the collective.
+    std::atomic<int> arrived{0}, phase1_failed{0};
+    // A failure AFTER the rendezvous (the collective itself, the stream synchronisation behind it) cannot be undone
+    // rank by rank: the failing worker aborts every communicator (ncclCommAbort releases ranks blocked in the
+    // collective) and the fleet refuses further calls.
+    std::atomic<bool> broken{false};
+    // failure injection for the rehearsal tests: HWMC_COMM_INJECT_FAIL=rank:phase[:count], read by hw_comm_create*
+    int inject_rank = -1, inject_phase = 0;
+    std::atomic<int> inject_left{0};
 };
-
-#define NCCL_TRY(cm, expr)                                                                              \
-    do {                                                                                                \
-        ncclResult_t r_ = (expr);                                                                       \
-        if (r_ != ncclSuccess) return fail(HW_E_HIP, "RCCL error [%s]: %s", #expr, (cm)->GetErrorString(r_)); \
-    } while (0)
 
 // shard [0, n) in contiguous blocks: rank g gets {offset, count}
 static void comm_shard(int64_t n, int g, int G, int64_t* off, int64_t* cnt)
@@ -1491,6 +1571,8 @@ static int comm_dispatch(hw_comm* cm, const std::function<int(int)>& job)
     {
         std::lock_guard<std::mutex> lk(cm->mu);
         cm->job = &job;
+        cm->arrived.store(0, std::memory_order_relaxed);          // (every worker of the previous job has returned)
+        cm->phase1_failed.store(0, std::memory_order_relaxed);
         cm->pending.store(G, std::memory_order_release);
         cm->generation.fetch_add(1, std::memory_order_acq_rel);
     }
@@ -1505,34 +1587,83 @@ static int comm_dispatch(hw_comm* cm, const std::function<int(int)>& job)
     return HW_OK;
 }
 
+static bool comm_inject(hw_comm* cm, int g, int phase)
+{
+    if (g != cm->inject_rank || phase != cm->inject_phase) return false;
+    return cm->inject_left.fetch_sub(1, std::memory_order_acq_rel) > 0;
+}
+
+// release every rank that may be blocked in a collective: called once, by the first worker that fails in phase 2
+static void comm_abort_all(hw_comm* cm)
+{
+    if (cm->broken.exchange(true, std::memory_order_acq_rel)) return;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (size_t i = 0; i < cm->comm.size(); i++) {
+        (void)hipSetDevice(cm->ctx[i]->device);
+        if (cm->CommAbort) (void)cm->CommAbort(cm->comm[i]);
+    }
+    (void)hipSetDevice(cur);
+}
+
 // enqueue(g, offset, count, d_out, stream) on every device (by that device's worker), then ONE all-reduce of
-// `count_out` doubles per device on the same stream; worker 0 also brings the reduced vector to the host
+// `count_out` doubles per device on the same stream; worker 0 also brings the reduced vector to the host.
+// Two phases with a rendezvous between them, see hw_comm: no rank enters the collective unless all ranks enqueued.
 template <typename F>
 static int comm_run(hw_comm* cm, int64_t n_units, int count_out, double* out, float* wall_ms, F enqueue)
 {
     if (count_out > kOutCap) return fail(HW_E_INVALID, "too many outputs");
+    if (cm->broken.load(std::memory_order_acquire))
+        return fail(HW_E_HIP, "this communicator was aborted after a device failed inside a collective: destroy it and create a new one");
     const int G = (int)cm->ctx.size();
     const auto t0 = std::chrono::steady_clock::now();
     const std::function<int(int)> job = [&](int g) -> int {
         hw_ctx* c = cm->ctx[g];
         int64_t off, cnt;
         comm_shard(n_units, g, G, &off, &cnt);
-        int rc = enqueue(g, off, cnt, cm->host_sum ? c->h_out_dev : c->d_out, c->stream);
-        if (rc) return rc;
-        if (cm->host_sum) {
-            HIP_TRY(hipStreamSynchronize(c->stream));          // the column pass stored the sums straight to pinned host memory
-            memcpy(&cm->host_slots[(size_t)g * kOutCap], c->h_out, count_out * sizeof(double));
+        // ---- phase 1: this device's kernels (the only part that can fail on one rank alone)
+        int rc = comm_inject(cm, g, 1) ? fail(HW_E_HIP, "injected failure on rank %d before the collective (HWMC_COMM_INJECT_FAIL)", g)
+                                       : enqueue(g, off, cnt, cm->host_sum ? c->h_out_dev : c->d_out, c->stream);
+        if (rc) cm->phase1_failed.fetch_add(1, std::memory_order_release);
+        cm->arrived.fetch_add(1, std::memory_order_acq_rel);
+        for (unsigned spins = 0; cm->arrived.load(std::memory_order_acquire) < G; spins++) {     // every worker runs this job: they all arrive
+            __builtin_ia32_pause();
+            if ((spins & 1023) == 1023) std::this_thread::yield();
+        }
+        if (cm->phase1_failed.load(std::memory_order_acquire) > 0) {
+            // all or nothing: NOBODY enters the collective.  Drain what this device was given and report; the healthy ranks
+            // return HW_OK and comm_dispatch hands the failing rank's text to the caller.
+            (void)hipStreamSynchronize(c->stream);
+            free_retired(c);
+            return rc;
+        }
+        // ---- phase 2: every rank has enqueued its kernels
+        hipError_t e = hipSuccess;
+        if (comm_inject(cm, g, 2)) {
+            rc = fail(HW_E_HIP, "injected failure on rank %d inside the collective phase (HWMC_COMM_INJECT_FAIL)", g);
+        } else if (cm->host_sum) {
+            e = hipStreamSynchronize(c->stream);               // the column pass stored the sums straight to pinned host memory
+            if (e == hipSuccess) memcpy(&cm->host_slots[(size_t)g * kOutCap], c->h_out, count_out * sizeof(double));
         } else {
             // one communicator per thread: no group call needed (each rank's call comes from its own thread, as in the
             // one-process-per-GPU layout)
-            NCCL_TRY(cm, cm->AllReduce(c->d_out, c->d_out, (size_t)count_out, ncclDouble, ncclSum, cm->comm[g], c->stream));
-            if (g == 0) HIP_TRY(hipMemcpyAsync(out, c->d_out, count_out * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            const ncclResult_t r = cm->AllReduce(c->d_out, c->d_out, (size_t)count_out, ncclDouble, ncclSum, cm->comm[g], c->stream);
+            if (r != ncclSuccess) rc = fail(HW_E_HIP, "RCCL error [ncclAllReduce]: %s", cm->GetErrorString(r));
+            if (rc == HW_OK && g == 0) e = hipMemcpyAsync(out, c->d_out, count_out * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+            if (rc == HW_OK && e == hipSuccess) e = hipStreamSynchronize(c->stream);
         }
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (rc == HW_OK && e != hipSuccess) rc = fail(HW_E_HIP, "HIP error behind the collective: %s", hipGetErrorString(e));
+        if (rc != HW_OK) {
+            if (!cm->host_sum) comm_abort_all(cm);             // the other ranks may be blocked in the all-reduce: release them
+            return rc;
+        }
+        if (cm->broken.load(std::memory_order_acquire)) return HW_OK;     // released by a peer's abort: its error is the one reported
         free_retired(c);
         return HW_OK;
     };
-    const int rc = comm_dispatch(cm, job);
+    int rc = comm_dispatch(cm, job);
+    if (rc == HW_OK && cm->broken.load(std::memory_order_acquire))
+        rc = fail(HW_E_HIP, "a device failed inside the collective; the communicator was aborted");
     if (rc == HW_OK && cm->host_sum)
         for (int k = 0; k < count_out; k++) {
             double t = 0.0;
@@ -1543,8 +1674,9 @@ static int comm_run(hw_comm* cm, int64_t n_units, int count_out, double* out, fl
     return rc;
 }
 
-// A request one device would refuse must be refused HERE, on the calling thread, for all of them: a worker that
-// returns before it has enqueued its all-reduce leaves the other ranks waiting in theirs for ever.
+// A request one device would refuse is refused HERE, on the calling thread, for all of them, before any device is
+// given work (cheap, and the error text names the request, not a rank); what only shows at run time on one device is
+// caught by comm_run's rendezvous.
 static int comm_check(hw_comm* cm, const hw_zbc_request* r)
 {
     for (hw_ctx* c : cm->ctx) {
@@ -1569,6 +1701,13 @@ int hw_comm_create_ex(int32_t n, hw_ctx* const* ctxs, int32_t flags, hw_comm** o
     *out = nullptr;
     hw_comm* cm = new (std::nothrow) hw_comm();
     if (!cm) return fail(HW_E_NOMEM, "out of host memory");
+    if (const char* inj = getenv("HWMC_COMM_INJECT_FAIL")) {            // rank:phase[:count] -- rehearsal tests only
+        int rk = -1, ph = 0, cnt = 1;
+        if (sscanf(inj, "%d:%d:%d", &rk, &ph, &cnt) >= 2 && (ph == 1 || ph == 2)) {
+            cm->inject_rank = rk; cm->inject_phase = ph;
+            cm->inject_left.store(cnt > 0 ? cnt : 1);
+        }
+    }
     if (flags == HW_COMM_HOST_SUM) {
         for (int i = 0; i < n; i++) {
             if (!ctxs[i]) { delete cm; return fail(HW_E_INVALID, "null context %d", i); }
@@ -1591,8 +1730,9 @@ int hw_comm_create_ex(int32_t n, hw_ctx* const* ctxs, int32_t flags, hw_comm** o
     cm->GroupStart = (decltype(cm->GroupStart))dlsym(cm->lib, "ncclGroupStart");
     cm->GroupEnd = (decltype(cm->GroupEnd))dlsym(cm->lib, "ncclGroupEnd");
     cm->CommDestroy = (decltype(cm->CommDestroy))dlsym(cm->lib, "ncclCommDestroy");
+    cm->CommAbort = (decltype(cm->CommAbort))dlsym(cm->lib, "ncclCommAbort");
     cm->GetErrorString = (decltype(cm->GetErrorString))dlsym(cm->lib, "ncclGetErrorString");
-    if (!cm->CommInitAll || !cm->AllReduce || !cm->GroupStart || !cm->GroupEnd || !cm->CommDestroy || !cm->GetErrorString) {
+    if (!cm->CommInitAll || !cm->AllReduce || !cm->GroupStart || !cm->GroupEnd || !cm->CommDestroy || !cm->CommAbort || !cm->GetErrorString) {
         delete cm;
         return fail(HW_E_HIP, "RCCL library lacks a required symbol");
     }
@@ -1628,6 +1768,7 @@ void hw_comm_destroy(hw_comm* cm)
     cm->cv_job.notify_all();
     for (std::thread& t : cm->workers) t.join();
     for (size_t i = 0; i < cm->comm.size(); i++) {      // (no communicators in HW_COMM_HOST_SUM mode)
+        if (cm->broken.load()) break;                    // ncclCommAbort has already released them
         (void)hipSetDevice(cm->ctx[i]->device);
         (void)cm->CommDestroy(cm->comm[i]);
     }

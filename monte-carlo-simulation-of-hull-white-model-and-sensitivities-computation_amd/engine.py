@@ -337,6 +337,13 @@ class HullWhiteEngine:
                                       out.ctypes.data_as(C.POINTER(C.c_uint32))))
         return out.reshape(n_blocks, 4)
 
+    def debug_exp2(self, x):
+        """The double engine's exp2 evaluated on the GPU (hw_debug_exp2)."""
+        x = np.ascontiguousarray(x, np.float64)
+        out = np.zeros_like(x)
+        L.check(self.lib.hw_debug_exp2(self._ctx, _dp(x), int(x.size), _dp(out)))
+        return out
+
 
 class HullWhitePipeline:
     """hw_pipe_*: a stream of independent pricing calls on one GPU with `queues` launches in flight (include/hw_mc.h).

@@ -76,6 +76,26 @@ def test_device_normals_vs_oracle_and_rocrand(setup, rocrand_vectors, golden):
     assert abs(z.var() - 1.0) < 4 * math.sqrt(2.0 / z.size)
 
 
+def test_device_exp2_of_a_double(setup):
+    """The double engine's exponential is v_exp_f32 on the float-rounded argument plus a first-order correction
+    (hw_exp2(double), csrc/hw_kernels.hpp; include/hw_mc.h HW_F64): against libm's exp2 over the arguments the path
+    produces (|x| = B r log2e, int r log2e: O(1); checked out to +-40) the relative error must stay below 1.2e-7
+    (v_exp_f32: 1 ulp of float) and its MEAN signed error below 1e-8 -- a biased exponential shifts every discount factor
+    the same way, which no amount of paths averages out (measured, tools/exp2_probe.py over 4 M arguments: max 8.4e-8,
+    sd 2.6e-8, mean -2.3e-9, i.e. three orders below the engine's 2e-6 parity bar).  The reference holds nothing that pins a per-path exp error (its
+    kernels are float32, common.cuh:337-343), so this is a property test, not a parity pin."""
+    e, _, _, _ = setup("head", "f64")
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.uniform(-3.0, 3.0, 1 << 18), rng.normal(0.0, 0.2, 1 << 18), rng.uniform(-40.0, 40.0, 1 << 16),
+                        np.array([0.0, -0.0, 1.0, -1.0, 0.5, 1e-30, -1e-30, 2.0 ** -30, 100.0, -100.0])])
+    got = e.debug_exp2(x)
+    rel = got / np.exp2(x) - 1.0
+    assert float(np.max(np.abs(rel))) < 1.2e-7, float(np.max(np.abs(rel)))
+    core = rel[: 1 << 19]
+    assert abs(float(core.mean())) < 1e-8, (core.mean(), core.std())
+    assert got[-10] == 1.0 and got[-9] == 1.0 and got[-8] == 2.0 and got[-7] == 0.5          # exact at 0, -0, 1, -1
+
+
 # ---- ZBC: the north-star kernel -----------------------------------------------------------------
 @pytest.mark.parametrize("profile", ["head", "readme"])
 @pytest.mark.parametrize("stepper", ["superposed", "reference"])

@@ -96,6 +96,58 @@ def test_q1_bond_price_matches_the_readme(setup):
     assert abs(README["P10"] - 0.876777) == pytest.approx(U_P, abs=1e-6)  # the budget used below is that published deviation
 
 
+def test_q1_checks_and_q2a_theta_recovery_against_the_readme(setup):
+    """The two reference-held outputs that round 2 left aside (README.md:15-26):
+
+        Q1  "P(0,0) = 1.000000, P(0,10) = 0.876844, f(0,0) = 1.21 %"  with the three range checks of 1_bond_pricing.cu:98-104
+        Q2a "Max Error: 1.56e-03 (at T=0), Mean Error: 2.49e-04, SUCCESS (< 0.01)"      (2_option_pricing.cu:49-67: the
+            errors are taken over the 11 printed maturities T = 0, 1, ..., 10, i.e. every SAVE_STRIDE-th of the 101)
+
+    reproduced with the reference's own pipeline at its own sample size -- GPU curve of 2^20 antithetic pairs ->
+    hw_average_and_forward (market_data.cuh:101-127) -> hw_recover_theta (2_option:14-35) -- under theta profile
+    "readme", 16 seeds.
+
+    What holds, and is asserted: the three range checks; SUCCESS; our errors stay INSIDE the README's (max <= 1.56e-3,
+    mean <= 2.49e-4: they are upper budgets, the README's run was noisier than HEAD's estimator can be, see below);
+    |f(0,0) - 1.21 %| within the 1.5e-4 the round-2 budget already allowed for that rate.
+
+    What cannot be pinned, and why (asserted as facts about HEAD's formulas so that the statement stays true): with the
+    forward-rate formula at HEAD, f(0,0) = -(ln P[1] - ln P[0]) / dT is an antithetic-pair estimate over [0, 0.1] whose
+    Monte Carlo scatter at 2^20 pairs is ~1e-8 -- it prints 1.1987 % for every seed, 1.20 % to the README's two decimals,
+    never 1.21 %; the theta error at T = 0 is then the deterministic 3.7e-4 of the one-sided difference, and the largest
+    of the 11 errors sits at T = 10 (the other one-sided end, 5-7e-4, where P(0,10)'s sampling error enters).  The README's
+    pair "1.21 %" and "1.56e-3 at T = 0" is self-consistent -- theta_rec(0) = (f[1] - f[0]) / dT + a f[0] gives an error of
+    1.5e-3 when f[0] = 0.01215 -- so both lines were printed by an earlier, noisier f(0,0) estimate, not by the source at
+    HEAD."""
+    hwmc, e, Pq, f = setup
+    p = e.params
+    worst_max, worst_mean, at_T, f00, err0 = 0.0, 0.0, [], [], []
+    idx = np.arange(0, p.n_mat, p.n_steps // (p.n_mat - 1))             # i = 0, SAVE_STRIDE, ... (2_option:49; common.cuh:29)
+    assert len(idx) == 11
+    for seed in range(16):
+        Psum = e.simulate_zcb(N, 31337 + 7919 * seed)
+        Pmc, fmc = e.compute_average_and_forward(Psum, 2 * N)
+        # the three checks of 1_bond_pricing.cu:98-104, the reference's own acceptance test for Q1
+        assert 0.99 < Pmc[0] < 1.01 and Pmc[0] == 1.0
+        assert 0.3 < Pmc[100] < 0.9
+        assert 0.01 < fmc[0] < 0.02
+        rec, orig, Ts = e.recover_theta(fmc)
+        err = np.abs(rec - orig)[idx]
+        assert float(err.max()) < 0.01                                   # "Recovery: SUCCESS" (2_option:63)
+        worst_max, worst_mean = max(worst_max, float(err.max())), max(worst_mean, float(err.mean()))
+        at_T.append(float(Ts[idx][int(err.argmax())]))
+        f00.append(float(fmc[0]))
+        err0.append(float(err[0]))
+    assert worst_max <= 1.56e-3 and worst_mean <= 2.49e-4, (worst_max, worst_mean)        # inside the README's figures
+    assert abs(np.mean(f00) - 0.0121) < U_F                              # 1.21 % within the stated budget ...
+    # ... and the facts behind "cannot be pinned to the printed digits":
+    # (float32 P[1] next to 1 has a quantum of 6e-8, i.e. 6e-7 on f(0,0) and 6e-6 on the T = 0 error: that, not sampling, is the spread)
+    assert max(f00) - min(f00) < 2e-6 and abs(100 * np.mean(f00) - 1.1987) < 2e-4 and all("%.2f" % (100 * v) == "1.20" for v in f00)
+    assert max(err0) - min(err0) < 2e-5 and abs(np.mean(err0) - 3.7e-4) < 1.5e-5          # T = 0: deterministic 3.7e-4, not 1.56e-3
+    assert set(at_T) == {10.0}                                           # the largest error sits at T = 10, not T = 0
+    assert 4e-4 < worst_max < 9e-4 and 0.8e-4 < worst_mean < 1.6e-4     # measured 5.3-6.1e-4 / 1.1e-4 (oracle: the same)
+
+
 def test_zbc_20_run_validation_matches_the_readme(setup):
     hwmc, e, Pq, f = setup
     P0S2 = README["P10"]                                              # 2_option:492: h_P[N_MAT-1]
