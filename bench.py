@@ -20,8 +20,9 @@ step's compute stream, so no compute stream ever waits for RCCL.  (--scaling wea
 Because the sample set depends only on (seed, global pair id), the reduced sums do not depend on N.
 
 Timing.  EXACTLY K steps are timed between barrier + torch.cuda.synchronize() on both sides, MAX over ranks; that
-region is repeated --regions times (fresh barriers each time) and `value` is the MEDIAN region, with the spread beside
-it: at 2^20 pairs a region lasts only K * 0.18 ms.
+region is repeated (fresh barriers each time) and `value` is the MEDIAN region, with the spread beside it: at 2^20 pairs a
+region lasts only K * 0.18 ms, so by default (--regions 0) it is repeated until the timed regions total >= 0.5 s
+(`timed_region_s` in the line; ~145 regions at N = 1), which also makes the timed work visible to an outside sampler.
 
 Pipelining.  The K steps are independent pricing batches, so each GPU alternates them over S contexts (S HIP streams,
 --streams, default 2): the drain of a launch's last waves (~11 us at 2^20 pairs) and the ~4 us it spends outside its waves
@@ -32,11 +33,18 @@ single-stream run, and the line carries the strictly serial rate ("serial") and 
 Side measurements in the same line (untimed, N = 1; --no-extras drops them): `long_region` (10 K steps between two
 synchronisations: what starting and draining the pipeline once per K steps costs), `library_pipeline` (the same K calls
 through the C ABI's own hw_pipe_zbc_moments: one function call, no torch), `other_stepper`, `runs20_single_launch`,
-`q1_curve_gpu`, `strong_scaling_reference`; `cpu_baseline` = the oracle on the host cores (the only use of oracle/ here).
+`q1_curve_gpu`, `q3_vega_gpu` (the reference's other two published rates, README.md:161-163), `strong_scaling_reference`;
+`cpu_baseline` = the oracle on the host cores (the only use of oracle/ here).
+
+VALU bound.  `valu.bound_cycles_per_block` is MEASURED, not modelled: tools/mix_bound.hip times the production loop's own
+instruction stream with its data dependencies removed (tools/gen_mix_bound.py) in shader-clock cycles; the production
+loop cannot issue faster, so valu.frac = bound / achieved <= 1.  bench.py runs the probe live (a child process, before this
+process touches the GPU) when tools/bin/mix_bound exists, else reads the newest profiles/rNN_mix_bound.json.
 """
 import argparse
 import glob
 import json
+import math
 import os
 import re
 import sys
@@ -58,6 +66,9 @@ VALU_MODEL = {
     "superposed_f64": {"full": 30, "half": 26, "quarter": 8},
 }
 MEASURED_ISSUE = {"full": 2.3, "half": 4.4, "quarter": 8.1}
+V100_PUBLISHED_Q1_MPATHS = 391.0   # reference README.md:161 (simulate_zcb, 2 x 2^20 paths x 1000 steps)
+V100_PUBLISHED_Q3_MPATHS = 509.0   # reference README.md:163 (simulate_sensitivity, 2^20 paths; src/3_sensitivity_analysis.cu:266)
+TIMED_TOTAL_S = 0.5                # --regions 0: repeat the K-step region until the timed regions total this much
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 V100_PUBLISHED_MPATHS = 1064.0  # BASELINE.md section 1 (reference README.md:44,162; one V100)
 
@@ -67,7 +78,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--regions", type=int, default=7, help="how many times the timed K-step region is repeated (median reported)")
+    ap.add_argument("--regions", type=int, default=0,
+                    help="how many times the timed K-step region is repeated (median reported); 0 = as many as make the timed "
+                         "regions total >= 0.5 s (at least 7, at most 400)")
     ap.add_argument("--paths-log2", type=int, default=20, help="antithetic pairs per step: per GPU for N = 1 and for --scaling weak (log2)")
     ap.add_argument("--total-log2", type=int, default=24, help="N > 1, --scaling strong: pairs per step over ALL GPUs (log2); BASELINE configs[3] = 24")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
@@ -159,6 +172,37 @@ def newest_pmc_summary(config_is_default):
         return None, None
 
 
+def mix_bound(live=True):
+    """The measured issue bound of the float (y, W) loop's instruction mix (tools/mix_bound.hip): live from tools/bin/mix_bound
+    when it is built -- call BEFORE this process initialises the GPU -- else the newest committed profiles/rNN_mix_bound.json."""
+    exe = os.path.join(ROOT, "tools", "bin", "mix_bound")
+    if live and os.path.exists(exe) and os.environ.get("HWMC_BENCH_NO_LIVE_BOUND") != "1":
+        import subprocess
+        try:
+            r = subprocess.run([exe, "200000", "--json"], capture_output=True, text=True, timeout=120)
+            for l in r.stdout.splitlines():
+                if l.startswith("{"):
+                    d = json.loads(l)
+                    d["source"] = "live: tools/bin/mix_bound 200000 --json, run by this process before it touched the GPU"
+                    return d
+        except (OSError, ValueError, subprocess.SubprocessError):
+            pass
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_mix_bound.json")):
+        m = re.match(r"r(\d+)_mix_bound\.json$", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    if best is None:
+        return None
+    try:
+        with open(best[1]) as fh:
+            d = json.load(fh)
+        d["source"] = "profiles/" + os.path.basename(best[1])
+        return d
+    except (OSError, ValueError):
+        return None
+
+
 def union_ms(spans):
     """Total length of the union of [start, end] intervals."""
     total, cur_a, cur_b = 0.0, None, None
@@ -178,6 +222,9 @@ def main():
     a = parse()
     import faulthandler
     faulthandler.dump_traceback_later(900, exit=True)  # a default run takes well under a minute: never sit in a hang
+    rank0 = int(os.environ.get("RANK", "0")) == 0
+    # the measured VALU issue bound (a child process on the GPU: before this process initialises HIP; rank 0, N = 1 only)
+    bound = mix_bound(live=rank0 and a.gpus == 1) if rank0 else None
     import torch                                       # first: libhw_hip.so then shares torch's HIP runtime
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -237,7 +284,7 @@ def main():
         engines.append(eng)
     e = engines[0]
     stepper = hwmc.HW_STEPPER_SUPERPOSED if a.stepper == "superposed" else hwmc.HW_STEPPER_REFERENCE
-    K, W, R = a.steps, a.warmup, max(1, a.regions)
+    K, W, R = a.steps, a.warmup, a.regions               # R = 0: decided after the first timed region (below)
     out = torch.zeros((K + W, 5), dtype=torch.float64, device=dev)
     B = max(1, a.allreduce_every) if a.allreduce_every > 0 else K
 
@@ -366,7 +413,10 @@ def main():
     # One HIP event pair brackets the K launches of a region: recorded on streams[0] before the first launch and, after
     # streams[0] has been made to wait for the other streams, behind the last one.
     elapsed_regions, region_ms_events = [], []
-    for _ in range(R):
+    r_done = 0
+    while True:
+        if R > 0 and r_done >= R:
+            break
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
         works = []
@@ -384,6 +434,14 @@ def main():
         elapsed_regions.append(time.perf_counter() - t0)   # every rank has contributed all its K steps; MAX over ranks below
         fence()
         region_ms_events.append(ev0.elapsed_time(ev1))
+        r_done += 1
+        if R <= 0:
+            # automatic region count: every rank must run the SAME number of regions (each holds barriers and, for N > 1,
+            # collectives), so it is derived from the MAX over ranks of the first region's time
+            t1 = torch.tensor([elapsed_regions[0]], dtype=torch.float64, device=cdev)
+            if dist_on:
+                dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+            R = int(min(400, max(7, math.ceil(TIMED_TOTAL_S / max(float(t1.item()), 1e-6)))))
     sums = out[W:].cpu().numpy()                           # the K all-reduced moment vectors of the timed steps
     if dist_on:                                            # MAX over ranks, region by region (one collective)
         t = torch.tensor(elapsed_regions, dtype=torch.float64, device=cdev)
@@ -429,8 +487,9 @@ def main():
         eng.profile_enable(0)                              # event pairs off: they cost queue bubbles
     # ... and the wall-clock rate without pipelining and without event pairs (median of the same number of regions)
     serial_regions = []
+    R_side = min(R, 15)                                    # the untimed side measurements repeat at most 15 times
     respin()
-    for _ in range(R):
+    for _ in range(R_side):
         torch.cuda.synchronize()
         ts = time.perf_counter()
         for i in range(K):
@@ -506,7 +565,7 @@ def main():
             while (time.perf_counter() - tp) * 1e3 < 60.0:
                 pipe.simulate_ZBC_batch(shard_n, seeds, path_offset=offset)
             got, ms_list = None, []
-            for _ in range(R):
+            for _ in range(R_side):
                 got, ms = pipe.simulate_ZBC_batch(shard_n, seeds, path_offset=offset, return_ms=True)
                 ms_list.append(ms / K)
             assert np.array_equal(got, sums), "hw_pipe_zbc_moments and the timed region disagree"
@@ -514,7 +573,7 @@ def main():
             extras["library_pipeline"] = {"api": "hw_pipe_zbc_moments", "queues": S, "steps": K, "ms_per_step": pm,
                                           "value": (2 * shard_n / pm) / 1000.0, "unit": "M paths/s", "tuned_ms_per_step": tuned_ms,
                                           "note": "K requests through the C ABI's pipe, host wall time inside the call (enqueue, one D2H "
-                                                  "copy of the K x 5 sums, one synchronisation), median of %d batches; sums identical to the timed region's" % R}
+                                                  "copy of the K x 5 sums, one synchronisation), median of %d batches; sums identical to the timed region's" % R_side}
     if world == 1 and not a.no_extras:
         # the OTHER stepper on the same workload: the reference's per-step arithmetic verbatim vs the superposed recursion
         other = hwmc.HW_STEPPER_REFERENCE if a.stepper == "superposed" else hwmc.HW_STEPPER_SUPERPOSED
@@ -557,7 +616,24 @@ def main():
             mq = float(np.median(msq))
             extras["q1_curve_gpu"] = {"pairs": 1 << 20, "grid_steps": 1000, "maturities": 100, "kernel_ms": mq,
                                       "value": (2 * (1 << 20) / mq) / 1000.0, "unit": "M paths/s",
-                                      "vs_v100_391": ((2 * (1 << 20) / mq) / 1000.0) / 391.0}
+                                      "vs_v100_391": ((2 * (1 << 20) / mq) / 1000.0) / V100_PUBLISHED_Q1_MPATHS}
+        # the Q3 pathwise-Vega kernel at BASELINE configs[2]'s size (2^20 single paths, 500 executed steps), metric exactly
+        # as src/3_sensitivity_analysis.cu:266: (N_PATHS / ms) / 1000 with the event pair around the kernel
+        respin()
+        tw = time.perf_counter()
+        while (time.perf_counter() - tw) * 1e3 < 80.0:
+            e.simulate_sensitivity(1 << 20, 1)
+        msv = []
+        for j in range(5):
+            e.simulate_sensitivity(1 << 20, 4242 + j)       # back-to-back pair: the second launch is the timed one
+            e.profile_enable(1)
+            e.simulate_sensitivity(1 << 20, 4242 + j)
+            msv.append(float(e.profile_read(1)[0]))
+        mv = float(np.median(msv))
+        extras["q3_vega_gpu"] = {"paths": 1 << 20, "grid_steps": a.grid_steps, "kernel_ms": mv, "value": ((1 << 20) / mv) / 1000.0,
+                                 "unit": "M paths/s", "vs_v100_509": (((1 << 20) / mv) / 1000.0) / V100_PUBLISHED_Q3_MPATHS,
+                                 "reference_metric": "throughput = (N_PATHS/ms)/1000, src/3_sensitivity_analysis.cu:266 (single paths, not pairs)",
+                                 "note": "pathwise Vega kernel alone on the chip, hipEvent pair around the path kernel, median of 5"}
         # strong-scaling reference: the N > 1 workload (2^total_log2 pairs per step) on this ONE GPU, same pipelining
         nref = 1 << a.total_log2
         if a.scaling == "strong" and nref != shard_n and a.stepper == "superposed":
@@ -605,9 +681,16 @@ def main():
         waves = (shard_n + 63) // 64
         simd_cycles = waves * (steps_exec / 4.0) * cyc_per_block
         simd_hz = info["compute_units"] * 4 * info["clock_mhz"] * 1e6
-        valu_frac = simd_cycles / (simd_hz * region_per_step * 1e-3)        # the chip over the timed region
-        valu_frac_iso = simd_cycles / (simd_hz * kiso * 1e-3)               # one launch alone on the chip
-        achieved_cyc = region_per_step * 1e-3 * (clock_mhz or info["clock_mhz"]) * 1e6 * info["compute_units"] * 4 / (waves * steps_exec / 4.0)
+        nominal_frac = simd_cycles / (simd_hz * region_per_step * 1e-3)     # nominal 2/4/8 model at the NOMINAL clock: not a bound
+        nominal_frac_iso = simd_cycles / (simd_hz * kiso * 1e-3)
+        # achieved shader-clock cycles per Philox block (4 steps of one pair) per SIMD, at the clock the chip HELD (in-kernel
+        # s_memtime / s_memrealtime probe), whole launch: prologue, epilogue, drain and the column pass included
+        mhz = clock_mhz or info["clock_mhz"]
+        wave_blocks = waves * (steps_exec / 4.0)            # a "block" = one Philox block (4 steps) of the 64 pairs of a wave
+        cyc_of = lambda ms: ms * 1e-3 * mhz * 1e6 * info["compute_units"] * 4 / wave_blocks
+        achieved_cyc, achieved_cyc_iso = cyc_of(region_per_step), cyc_of(kiso)
+        use_bound = bound if (bound and a.stepper == "superposed" and a.precision == "f32") else None
+        bcyc = use_bound["bound_cycles_per_block"] if use_bound else None
         if world == 1:
             workload = ("Q2b option_pricing (BASELINE configs[1]): 2^%d antithetic pairs x %d-step grid (%d executed to S1=5), "
                         "optimal-beta control variate, 1 x MI355X" % (a.paths_log2, a.grid_steps, steps_exec))
@@ -625,6 +708,7 @@ def main():
             "baseline": {"value": V100_PUBLISHED_MPATHS, "unit": "M paths/s", "hardware": "1x Tesla V100",
                          "source": "reference README.md:44,162 (single un-warmed launch)"},
             "dtype": a.precision, "data": "synthetic",
+            "timed_region_s": round(float(sum(elapsed_regions)), 4),
             "value_spread": {"timed_regions": R, "steps_per_region": K, "min": round(vals[0], 2), "median": round(value, 2),
                              "max": round(vals[-1], 2), "region_ms": [round(x * 1e3, 4) for x in elapsed_regions],
                              "note": "`value` is the median region; every region times exactly K steps between barrier + synchronize"},
@@ -661,20 +745,33 @@ def main():
                                                             "replay runs slower than the timed region",
                          "algorithmic_bytes_per_launch": algo_bytes, "launch_geometry": geo,
                          "note": "stateless Philox: the path kernel has ~0 algorithmic HBM traffic; the binding roof is VALU issue (see valu)"},
-            "valu": {"bound": "valu-issue", "model": "serial issue: 2 / 4 / 8 cycles per single-rate / multiply-convert-f64 / transcendental wave64 instruction per SIMD",
-                     "issue_cycles_per_wave_per_4_steps": cyc_per_block, "instr_per_4_steps": vm,
-                     "achieved_cycles_per_wave_per_4_steps": achieved_cyc,
+            "valu": {"bound": "valu-issue",
+                     "how": "bound = shader-clock cycles per Philox block per SIMD of the production loop's own instruction stream with its "
+                            "data dependencies removed, fastest of all orderings and occupancies tried (tools/mix_bound.hip, generated from "
+                            "the gfx950 listing by tools/gen_mix_bound.py); achieved = launch time x in-kernel clock x SIMDs / pair-blocks, "
+                            "everything a launch does included; frac = bound / achieved, <= 1 by construction",
+                     "instr_per_4_steps": vm,
+                     "bound_cycles_per_block": bcyc,
+                     "bound_source": use_bound["source"] if use_bound else None,
+                     "bound_at": use_bound.get("bound_at") if use_bound else None,
+                     "exclusive_classes_floor": ({"nominal_4_4_8": use_bound["exclusive_classes_nominal_floor"],
+                                                  "measured": use_bound["exclusive_classes_measured"]} if use_bound else None),
+                     "production_loop_in_the_harness_cycles": use_bound.get("real_loop_cycles_per_block") if use_bound else None,
+                     "achieved_cycles_per_block_isolated_launch": achieved_cyc_iso,
+                     "achieved_cycles_per_block_timed_region": achieved_cyc,
+                     "frac": (bcyc / achieved_cyc_iso) if bcyc else None,
+                     "frac_basis": "isolated launch (kernel_ms_avg: the quantity rocprofv3 --stats reports for --streams 1)",
+                     "frac_timed_region": (bcyc / achieved_cyc) if bcyc else None,
                      "clock_mhz_nominal": info["clock_mhz"], "clock_mhz_in_kernel": clock_mhz,
-                     "frac_of_nominal_clock_peak": valu_frac,
-                     "frac_at_measured_clock": (valu_frac * info["clock_mhz"] / clock_mhz) if clock_mhz else None,
-                     "frac_of_nominal_clock_peak_isolated_launch": valu_frac_iso,
-                     "note": "fractions compare the model's cycles with the chip time per step of the timed region (isolated: with one "
-                             "launch alone on the chip); they can pass 1 because part of v_cvt_f32_u32 hides under single-rate ops "
-                             "(profiles: coissue probe).  Single-class issue rates measured alone: %s cycles." % MEASURED_ISSUE},
+                     "nominal_serial_model": {"cycles_per_block_2_4_8": cyc_per_block,
+                                              "ratio_to_timed_region_at_nominal_clock": nominal_frac,
+                                              "ratio_to_isolated_launch_at_nominal_clock": nominal_frac_iso,
+                                              "note": "rounds 1-2 quoted these ratios as a roofline fraction; the model is NOT a bound (classes of "
+                                                      "different waves partly co-issue: it was exceeded) and is kept for continuity only"}},
             "kernel_Mpaths_per_sec_isolated_launch": (2 * shard_n / kiso) / 1000.0,
             "serial": {"streams_per_gpu": 1, "ms_per_step": serial_ms, "value": (2 * shard_n / serial_ms) / 1000.0,
                        "vs_baseline": (2 * shard_n / serial_ms) / 1000.0 / V100_PUBLISHED_MPATHS,
-                       "unit": "M paths/s per GPU", "note": "same K launches strictly one after another on one stream, no all-reduce; median of %d regions" % R},
+                       "unit": "M paths/s per GPU", "note": "same K launches strictly one after another on one stream, no all-reduce; median of %d regions" % R_side},
             "device": info["name"],
         }
         line.update(extras)

@@ -68,8 +68,16 @@ def test_bench_default_line_carries_the_side_measurements():
     at configs[0]'s size, the 2^24-pair strong-scaling reference, the 10 K-step region and the same K calls through the
     library's own pipe (whose sums bench.py itself compares with the timed region's), all as throughputs in the metric's unit."""
     d = _bench("--steps", "6", "--regions", "3")
-    for key in ("other_stepper", "runs20_single_launch", "q1_curve_gpu", "strong_scaling_reference", "serial", "long_region", "library_pipeline"):
+    for key in ("other_stepper", "runs20_single_launch", "q1_curve_gpu", "q3_vega_gpu", "strong_scaling_reference", "serial", "long_region", "library_pipeline"):
         assert d[key]["value"] > 0, key
+    # the three rates the reference publishes (README.md:161-163), each in its own metric: Q2b = value, Q1, Q3
+    assert d["q3_vega_gpu"]["paths"] == 1 << 20 and d["q3_vega_gpu"]["value"] > 509.0 and d["q3_vega_gpu"]["vs_v100_509"] > 1.0
+    # the VALU bound is MEASURED (tools/mix_bound.hip, live or the committed profile) and the launch cannot beat it
+    v = d["valu"]
+    assert v["bound_cycles_per_block"] and 185.0 < v["bound_cycles_per_block"] < 200.0, v
+    assert 0.5 < v["frac"] <= 1.0 and 0.5 < v["frac_timed_region"] <= 1.0, v
+    assert v["exclusive_classes_floor"]["nominal_4_4_8"] == 144 and v["achieved_cycles_per_block_isolated_launch"] > v["bound_cycles_per_block"]
+    assert d["timed_region_s"] > 0
     assert d["long_region"]["steps"] == 60 and d["library_pipeline"]["api"] == "hw_pipe_zbc_moments" and d["library_pipeline"]["steps"] == 6
     assert d["strong_scaling_reference"]["pairs_per_step"] == 1 << 24 and d["config"]["pairs_per_step"] == 1 << 20
     assert d["scaling"] == "strong" and d["config"]["effective_paths"] == 2 << 20
