@@ -176,7 +176,8 @@ def mix_bound(live=True):
     """The measured issue bound of the float (y, W) loop's instruction mix (tools/mix_bound.hip): live from tools/bin/mix_bound
     when it is built -- call BEFORE this process initialises the GPU -- else the newest committed profiles/rNN_mix_bound.json."""
     exe = os.path.join(ROOT, "tools", "bin", "mix_bound")
-    if live and os.path.exists(exe) and os.environ.get("HWMC_BENCH_NO_LIVE_BOUND") != "1":
+    traced = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if live and not traced and os.path.exists(exe) and os.environ.get("HWMC_BENCH_NO_LIVE_BOUND") != "1":   # (never a child under a profiler)
         import subprocess
         try:
             r = subprocess.run([exe, "200000", "--json"], capture_output=True, text=True, timeout=120)
@@ -380,11 +381,13 @@ def main():
     torch.cuda.synchronize()
     torch.cuda.set_stream(streams[0])
 
-    def enqueue(i, seed, dst, n_streams=S, which=stepper, n=None, off=None, eng_list=None):
+    def enqueue(i, seed, dst, n_streams=S, which=stepper, n=None, off=None, eng_list=None, own_stream=False):
+        """own_stream: the context's own stream instead of this process's torch stream (no tail-event record at the end of the
+        call: include/hw_mc.h, 'Stream lifetime' -- 3 us per call when nothing else is in flight, profiles/r03_seal_cost_probe.txt)."""
         k = i % n_streams
         (eng_list or engines)[k].enqueue_ZBC(dst.data_ptr(), shard_n if n is None else n, seed,
                                              path_offset=offset if off is None else off, stepper=which,
-                                             stream=streams[k].cuda_stream)
+                                             stream=None if own_stream else streams[k].cuda_stream)
         return k
 
     reducer = hwmc.parallel.StepReducer(a.allreduce_every, K + W,
@@ -486,17 +489,19 @@ def main():
     for eng in engines:
         eng.profile_enable(0)                              # event pairs off: they cost queue bubbles
     # ... and the wall-clock rate without pipelining and without event pairs (median of the same number of regions)
-    serial_regions = []
+    serial_regions, serial_caller_regions = [], []
     R_side = min(R, 15)                                    # the untimed side measurements repeat at most 15 times
     respin()
-    for _ in range(R_side):
-        torch.cuda.synchronize()
-        ts = time.perf_counter()
-        for i in range(K):
-            enqueue(i, 1234 + 12345 * i, scratch[i], n_streams=1)
-        torch.cuda.synchronize()
-        serial_regions.append((time.perf_counter() - ts) * 1e3 / K)
+    for own in (False, True):                              # on this process's stream, then on the context's own stream
+        for _ in range(R_side):
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for i in range(K):
+                enqueue(i, 1234 + 12345 * i, scratch[i], n_streams=1, own_stream=own)
+            torch.cuda.synchronize()
+            (serial_regions if own else serial_caller_regions).append((time.perf_counter() - ts) * 1e3 / K)
     serial_ms = float(np.median(serial_regions))
+    serial_caller_ms = float(np.median(serial_caller_regions))
     if world == 1:
         assert np.array_equal(scratch[:K].cpu().numpy(), sums), "the stream count changed the sums"
     clock_mhz = e.profile_clock_mhz() if a.stepper == "superposed" else None
@@ -771,7 +776,10 @@ def main():
             "kernel_Mpaths_per_sec_isolated_launch": (2 * shard_n / kiso) / 1000.0,
             "serial": {"streams_per_gpu": 1, "ms_per_step": serial_ms, "value": (2 * shard_n / serial_ms) / 1000.0,
                        "vs_baseline": (2 * shard_n / serial_ms) / 1000.0 / V100_PUBLISHED_MPATHS,
-                       "unit": "M paths/s per GPU", "note": "same K launches strictly one after another on one stream, no all-reduce; median of %d regions" % R_side},
+                       "unit": "M paths/s per GPU", "on_a_caller_stream_ms_per_step": serial_caller_ms,
+                       "note": "same K launches strictly one after another on the context's own stream, no all-reduce; median of %d regions.  "
+                               "on_a_caller_stream: the same through a stream of the caller's, where every call ends with one hipEventRecord "
+                               "(the stream-lifetime rule of include/hw_mc.h)" % R_side},
             "device": info["name"],
         }
         line.update(extras)

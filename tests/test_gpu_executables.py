@@ -148,12 +148,13 @@ def test_reduction_benchmark_target(built, tmp_path):
 def test_throughput_driver_over_the_c_abi(built, tmp_path):
     """bin/throughput: the headline metric from plain C++ (no Python, no torch in the process): 20 pricing calls of 2^20
     pairs made synchronously and through hw_pipe_* with two queues in flight; the program itself compares the sums bit
-    for bit.  A loose floor (10 000 M paths/s; the north-star bar is 10 640, the measured figure 12 100+) is asserted on the pipelined figure."""
+    for bit.  Only the ORDERING of the two rates is asserted here; the absolute bar (10 640 M paths/s = 10x the V100) is a
+    perf claim and lives in tests/test_perf_claims.py (-m perf), so a slow box cannot fail the correctness suite."""
     r = _run("throughput", tmp_path, "--theta-profile", "readme")
     assert "sums identical: yes" in r.stdout and "FAILED" not in r.stdout
     j = json.loads([line for line in r.stdout.splitlines() if line.startswith("{")][-1])
     assert j["calls"] == 20 and j["queues"] == 2 and j["pairs_per_call"] == 1 << 20
-    assert j["pipelined"] > 10_000.0 and j["pipelined"] > j["synchronous"] > 5_000.0, j   # measured 12 100-12 170 and 10 300-10 430; the bar leaves room for a slow box
+    assert j["pipelined"] > j["synchronous"] > 0.0, j                        # measured 12 100-12 170 and 10 300-10 430
     price = float(r.stdout.split("ZBC price of call 0:")[1].split()[0])
     assert abs(price - 0.03544557) < 2e-4                                   # Jamshidian, readme profile (one run of 2^20 pairs)
     small = _run("throughput", tmp_path, "--paths-log2", "12", "--calls", "3", "--queues", "3", "--batches", "2", "--precision", "f64")

@@ -89,5 +89,4 @@ def test_two_queues_beat_synchronous_calls(hwmc_mod, market):
             for s in seeds:
                 e.simulate_ZBC_control_variate(n, s)
             sync.append((time.perf_counter() - t0) * 1e3 / len(seeds))
-        assert piped < min(sync), (piped, sync)
-        assert 2 * n / piped / 1e3 > 10_000.0                                # measured 12 100+ (north-star bar: 10 640); loose floor for a slow box
+        assert piped < min(sync), (piped, sync)                              # (the absolute bar lives in tests/test_perf_claims.py, -m perf)

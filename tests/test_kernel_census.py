@@ -189,3 +189,38 @@ def test_other_kernels_have_no_scratch_and_full_occupancy(listing):
                      ("vega_pathwise_kernelIdLi1E", 8), ("zbc_superposed_kernelIdLi3ELi1E", 6), ("zcb_curve_kernelIdE", 8)):
         _, meta = _kernel(listing, pat)
         assert meta["ScratchSize"] == 0 and meta["Occupancy"] >= occ, (pat, meta)
+
+
+def test_the_issue_bound_probe_times_the_production_loop():
+    """bench.py's valu.bound_cycles_per_block comes from tools/mix_bound.hip, whose loop bodies (tools/mix_bound_body.inc)
+    are GENERATED from the production kernel's gfx950 listing with the data dependencies removed (tools/gen_mix_bound.py).
+    The committed .inc must be what the current sources generate -- a change of the hot loop that is not followed by a
+    new probe run shows up here, without a GPU -- and the census the bound is quoted for is the loop's: 32 single-rate,
+    20 half-rate (16 v_mad_u64_u32 + 4 v_cvt_f32_u32), 8 quarter-rate instructions per Philox block, twice that for the
+    two-pairs-per-thread loop; the REAL variants are the production loops verbatim."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_mix_bound
+    text = gen_mix_bound.generate()
+    committed = open(os.path.join(ROOT, "tools", "mix_bound_body.inc")).read()
+    assert text == committed, "tools/mix_bound_body.inc is stale: python tools/gen_mix_bound.py, then re-run tools/bin/mix_bound on the GPU"
+    for name, val in (("PROD1_FULL", 32), ("PROD1_HALF", 20), ("PROD1_QUARTER", 8), ("PROD2_FULL", 64), ("PROD2_HALF", 40), ("PROD2_QUARTER", 16)):
+        assert re.search(r"#define MIX_CENSUS_%s %d\n" % (name, val), committed), name
+    # a dependency-free twin never reads what the loop writes: sources v0-v7 (+ SGPRs, literals), destinations v8-v39
+    body = committed.split("#define MIX_BODY_PROD1 ")[1].split("#define MIX_CLOBBERS_PROD1")[0]
+    n_valu = 0
+    for line in re.findall(r'"(v_[^"]*?)\\n', body):
+        ops = [o.strip() for o in line[len(line.split()[0]):].split(",")]
+        dest = [int(x) for x in re.findall(r"\d+", ops[0].split(":")[0])]
+        assert 8 <= dest[0] <= 39, line
+        first_src = 2 if line.startswith("v_mad_u64_u32") else 1
+        for o in ops[first_src:]:
+            for m in re.finditer(r"\bv\[?(\d+)", o):
+                assert int(m.group(1)) <= 7, line
+        n_valu += 1
+    assert n_valu == 60
+    # the committed measurement was taken for this census
+    import json
+    prof = json.load(open(os.path.join(ROOT, "profiles", "r03_mix_bound.json")))
+    assert prof["census_per_block"] == {"full": 32, "half": 20, "quarter": 8}
+    assert 144.0 <= prof["exclusive_classes_measured"] < prof["bound_cycles_per_block"] <= prof["nominal_serial_model"] == 208
+    assert abs(prof["real_loop_cycles_per_block"]["one_pair_per_thread"] - prof["bound_cycles_per_block"]) < 1.0

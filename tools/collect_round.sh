@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/collect_$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
-step() { echo "== $1"; shift; timeout -k 10 "$@" || { echo "step failed: rc=$?"; exit 1; }; }
+step() { echo "== $1" >&2; shift; timeout -k 10 "$@" || { echo "step failed: rc=$?" >&2; exit 1; }; }
 step "size scan zbc"  200 python tools/size_scan.py --kernel zbc --rounds 7 > "$OUT/size_scan_zbc.txt" 2>&1
 step "size scan zcb"  300 python tools/size_scan.py --kernel zcb --rounds 7 > "$OUT/size_scan_zcb.txt" 2>&1
 step "size scan vega" 200 python tools/size_scan.py --kernel vega --rounds 7 > "$OUT/size_scan_vega.txt" 2>&1
@@ -20,6 +20,10 @@ step "stress f32" 200 python tools/time_kernels.py --log2 26 --grid-steps 4000 -
 step "stress f64" 200 python tools/time_kernels.py --log2 26 --grid-steps 4000 --reps 3 --precision f64 > "$OUT/stress_f64.txt" 2>&1
 step "curve event cost" 200 python tools/curve_event_cost.py --P 1 > "$OUT/curve_event_cost_p1.txt" 2>&1
 step "readme pin" 200 python tools/readme_pin_report.py > "$OUT/readme_pin.txt" 2>&1
+step "mix bound" 100 tools/bin/mix_bound > "$OUT/mix_bound.txt" 2>&1
+step "mix bound json" 100 tools/bin/mix_bound --json > "$OUT/mix_bound.json" 2>&1
+step "seal cost" 100 python tools/seal_cost_probe.py > "$OUT/seal_cost_probe.txt" 2>&1
+step "throughput cpp" 100 ./bin/throughput --theta-profile readme > "$OUT/throughput_cpp.txt" 2>&1
 ( for k in zbc zbc1 zcb1; do timeout -k 5 60 tools/bin/timeline_probe 20 512 $k || exit 1; done ) > "$OUT/timeline_probe.txt" 2>&1 || { echo "timeline failed"; exit 1; }
 step "bench sizes" 600 python tools/bench_sizes.py > "$OUT/bench_size_table.txt" 2>&1
 echo "== rocprofv3 passes"
