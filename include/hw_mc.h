@@ -134,7 +134,13 @@ int  hw_set_launch(hw_ctx* ctx, int32_t block_size, int32_t max_blocks_per_cu, i
 
 /* ---- hot path -------------------------------------------------------------------------- */
 /* out[5] = {sum X, sum Y, sum X^2, sum Y^2, sum XY} over 2*n_pairs samples (double).
- * kernel_ms (may be NULL): hipEvent time of the launch(es), as 2_option:131-144 measures it. */
+ * kernel_ms (may be NULL): hipEvent time of the launch(es), as 2_option:131-144 measures it.
+ * All synchronous entry points (this one, _runs, _scenarios, hw_zcb_curve, hw_vega_pathwise*): the column pass stores
+ * the results straight into pinned host memory.  With kernel_ms = NULL no event pair is recorded and the call returns
+ * the moment its results have landed: the host polls completion stamps the column pass writes behind them (for at
+ * most ~300 us, then it falls back to hipStreamSynchronize; HWMC_SPIN_WAIT=0 disables the polling) -- 0.1955 instead
+ * of 0.2019 ms per 2^20-pair call, profiles/r03_sync_call_probe.txt.  With kernel_ms the call records the pair and waits
+ * for the stream, as before. */
 int  hw_zbc_moments(hw_ctx* ctx, const hw_zbc_request* req, double out[5], float* kernel_ms);
 
 /* Same, enqueue only: results land in d_out (DEVICE pointer, 5 doubles) in stream order on

@@ -85,6 +85,15 @@ struct hw_ctx {
     // device->host copy behind it (a blit kernel of its own: ~4 us + a launch gap per call, rocprofv3 of bin/q2).
     double* h_out = nullptr;          // host address
     double* h_out_dev = nullptr;      // the address the device uses for it
+    // ... followed by kOutCap 8-byte completion stamps: the column pass of a synchronous call publishes the call's sequence
+    // number behind each result it stores, and the host spins on those for a short while before it falls back to the
+    // stream synchronisation (whose wake-up costs several microseconds): timed_sync
+    unsigned long long* h_stamps = nullptr;      // host address
+    unsigned long long* h_stamps_dev = nullptr;  // device address; nullptr outside a synchronous call
+    unsigned long long stamp_seq = 0;
+    unsigned long long* stamp_arm = nullptr;     // set by timed_sync for the duration of its enqueue
+    int stamped = 0;                              // how many stamps the enqueue asked the column pass for (0: none, fall back)
+    int spin_wait = 1;                            // env HWMC_SPIN_WAIT=0: always hipStreamSynchronize (A/B)
     double* d_scale = nullptr;        // per-column scale for the curve (n_mat doubles)
     float* d_drift = nullptr;         // float table for the reference stepper / sample paths
     unsigned* d_ticket = nullptr;     // grid_sum_finish ticket counter (self re-arming)
@@ -282,11 +291,12 @@ int effective_ilp(const hw_ctx* c, int64_t n_units, int n_steps, double e, int n
 }
 
 // second launch of the default two-launch finish (no-op when the kernel finished in-launch)
-int finish_columns(hw_ctx* c, hipStream_t st, int rows, int ncol, double* d_out, int n_groups = 1)
+int finish_columns(hw_ctx* c, hipStream_t st, int rows, int ncol, double* d_out, int n_groups = 1, bool finished_in_kernel = false)
 {
-    if (c->single_launch && n_groups == 1) return HW_OK;
+    if (finished_in_kernel) return HW_OK;
     hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(ncol * n_groups), dim3(256), 0, st, (const double*)c->d_partials, rows,
-                       ncol, 1, (const double*)nullptr, -1.0, d_out, ncol);
+                       ncol, 1, (const double*)nullptr, -1.0, d_out, ncol, c->stamp_arm, c->stamp_seq);
+    if (c->stamp_arm) c->stamped = ncol * n_groups;
     HIP_TRY(hipGetLastError());
     return HW_OK;
 }
@@ -367,7 +377,10 @@ int launch_zbc_superposed(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, co
     a.clk = c->prof_cap > 0 ? c->d_clk : nullptr;
     a.blocks_per_run = (uint32_t)g.grid;
     a.seed_stride = seed_stride;
-    unsigned* tk = (c->single_launch && n_runs == 1) ? c->d_ticket : nullptr;
+    // (measured and rejected, profiles/r03_sync_call_probe.txt: finishing IN the kernel for the polled synchronous calls -- no
+    //  column-pass launch -- 0.1973 against 0.1962 ms per call: the ticket finish costs the kernel more than the launch it saves)
+    const bool in_kernel = n_runs == 1 && c->single_launch;
+    unsigned* tk = in_kernel ? c->d_ticket : nullptr;
     prof_mark(c, st, 0);
     if (ilp == 2)
         hipLaunchKernelGGL((hwk::zbc_superposed_kernel<REAL, NSCEN, 2>), dim3(total_grid), dim3(g.block), 0, st, a, c->d_partials, tk, d_out);
@@ -375,7 +388,7 @@ int launch_zbc_superposed(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, co
         hipLaunchKernelGGL((hwk::zbc_superposed_kernel<REAL, NSCEN, 1>), dim3(total_grid), dim3(g.block), 0, st, a, c->d_partials, tk, d_out);
     prof_mark(c, st, 1);
     HIP_TRY(hipGetLastError());
-    return finish_columns(c, st, g.grid, 5 * NSCEN, d_out, n_runs);
+    return finish_columns(c, st, g.grid, 5 * NSCEN, d_out, n_runs, in_kernel);
 }
 
 int launch_zbc_reference(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, const Scenario& s,
@@ -406,7 +419,8 @@ int launch_zbc_reference(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, con
     a.A = (float)s.A;
     a.B = (float)s.B;
     a.K = (float)r->K;
-    unsigned* tk = c->single_launch ? c->d_ticket : nullptr;
+    const bool in_kernel = c->single_launch != 0;
+    unsigned* tk = in_kernel ? c->d_ticket : nullptr;
     prof_mark(c, st, 0);
     if (c->table_in_lds)
         hipLaunchKernelGGL(hwk::zbc_reference_kernel<1>, dim3(g.grid), dim3(g.block),
@@ -417,7 +431,7 @@ int launch_zbc_reference(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, con
                            (const float*)c->d_drift, c->d_partials, tk, d_out);
     prof_mark(c, st, 1);
     HIP_TRY(hipGetLastError());
-    return finish_columns(c, st, g.grid, 5, d_out);
+    return finish_columns(c, st, g.grid, 5, d_out, 1, in_kernel);
 }
 
 int zbc_enqueue_body(hw_ctx* c, const hw_zbc_request* r, int n_scen, const double* sigma,
@@ -516,8 +530,9 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
         prof_mark(c, st, 1);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(n_mat), dim3(256), 0, st, (const double*)c->d_partials,
-                           g.grid, n_mat, 1, (const double*)c->d_scale, 2.0 * (double)n_pairs, d_P_sum, n_mat);
+                           g.grid, n_mat, 1, (const double*)c->d_scale, 2.0 * (double)n_pairs, d_P_sum, n_mat, c->stamp_arm, c->stamp_seq);
         HIP_TRY(hipGetLastError());
+        if (c->stamp_arm) c->stamped = n_mat;
         return HW_OK;
     }
     const Geometry g = geometry(c, n_pairs, 1, true);
@@ -541,8 +556,9 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
     prof_mark(c, st, 1);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(hwk::finalize_columns_kernel, dim3(n_mat), dim3(256), 0, st, (const double*)c->d_partials,
-                       g.grid, n_mat, 1, (const double*)c->d_scale, 2.0 * (double)n_pairs, d_P_sum, n_mat);
+                       g.grid, n_mat, 1, (const double*)c->d_scale, 2.0 * (double)n_pairs, d_P_sum, n_mat, c->stamp_arm, c->stamp_seq);
     HIP_TRY(hipGetLastError());
+    if (c->stamp_arm) c->stamped = n_mat;
     return HW_OK;
 }
 
@@ -590,7 +606,8 @@ int launch_vega(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset,
     a.cD = (REAL)c->vega_cDn;
     a.s_over_sigma = (REAL)(s.k.sig_st / p.sigma * hwk::kBmScale);
     a.zs = (REAL)(s.k.dt * s.k.sig_st / p.sigma * hwk::kBmScale);
-    unsigned* tk = (c->single_launch && n_runs == 1) ? c->d_ticket : nullptr;
+    const bool in_kernel = n_runs == 1 && c->single_launch;
+    unsigned* tk = in_kernel ? c->d_ticket : nullptr;
     prof_mark(c, st, 0);
     if (ilp == 2)
         hipLaunchKernelGGL((hwk::vega_pathwise_kernel<REAL, 2>), dim3(total_grid), dim3(g.block), 0, st, a, c->d_partials, tk, d_out);
@@ -598,7 +615,7 @@ int launch_vega(hw_ctx* c, int64_t n_paths, uint64_t seed, uint64_t path_offset,
         hipLaunchKernelGGL((hwk::vega_pathwise_kernel<REAL, 1>), dim3(total_grid), dim3(g.block), 0, st, a, c->d_partials, tk, d_out);
     prof_mark(c, st, 1);
     HIP_TRY(hipGetLastError());
-    return finish_columns(c, st, g.grid, 1, d_out, n_runs);
+    return finish_columns(c, st, g.grid, 1, d_out, n_runs, in_kernel);
 }
 
 // run `enqueue(d_out, stream)` on the context stream between events, copy n doubles back
@@ -607,13 +624,37 @@ int timed_sync(hw_ctx* c, int n_out, double* out, float* kernel_ms, F enqueue)
 {
     if (n_out > kOutCap) return fail(HW_E_INVALID, "too many outputs");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    // The event pair is recorded only for a caller who asked for the time: each record is a barrier packet of its own on
+    // the queue, ~3 us of a synchronous 2^20-pair call (profiles/r03_sync_call_probe.txt).
+    if (kernel_ms) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    // Without the event pair the host need not wait for the runtime either: the column pass stamps every result it stores
+    // into the pinned host buffer, and the call returns when all stamps of THIS call have arrived (spin for at most
+    // ~300 us -- the order of the stream synchronisation's own active wait -- then fall back to hipStreamSynchronize).
+    const bool spin = c->spin_wait && !kernel_ms;
+    c->stamp_seq++;
+    c->stamp_arm = spin ? c->h_stamps_dev : nullptr;
+    c->stamped = 0;
     int rc = enqueue(c->h_out_dev, c->stream);
+    c->stamp_arm = nullptr;
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (kernel_ms) HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    bool arrived = false;
+    if (spin && c->stamped == n_out) {
+        const auto give_up = std::chrono::steady_clock::now() + std::chrono::microseconds(300);
+        const volatile unsigned long long* st = c->h_stamps;
+        for (unsigned spins = 0;; spins++) {
+            int k = 0;
+            while (k < n_out && __atomic_load_n(&st[k], __ATOMIC_ACQUIRE) == c->stamp_seq) k++;
+            if (k == n_out) { arrived = true; break; }
+            __builtin_ia32_pause();
+            if ((spins & 63) == 63 && std::chrono::steady_clock::now() > give_up) break;
+        }
+    }
+    if (!arrived) HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(out, c->h_out, n_out * sizeof(double));
-    free_retired(c);       // the context's stream has waited for every earlier launch of the context (use_stream)
+    // (retired workspaces: hipFree synchronises the device itself; every launch that used them precedes the column pass
+    //  whose results have arrived)
+    free_retired(c);
     if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, c->ev0, c->ev1));
     return HW_OK;
 }
@@ -686,8 +727,14 @@ int hw_create(const hw_params* p, int device, hw_ctx** out)
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&c->d_out, kOutCap * sizeof(double));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_out, kOutCap * sizeof(double), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_out, 2 * kOutCap * sizeof(double), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c->h_out_dev, c->h_out, 0);
+    if (e == hipSuccess) {
+        c->h_stamps = reinterpret_cast<unsigned long long*>(c->h_out + kOutCap);
+        c->h_stamps_dev = reinterpret_cast<unsigned long long*>(c->h_out_dev + kOutCap);
+        memset(c->h_stamps, 0, kOutCap * sizeof(unsigned long long));
+    }
+    if (const char* m = getenv("HWMC_SPIN_WAIT")) c->spin_wait = atoi(m) ? 1 : 0;
     if (e == hipSuccess) e = hipMalloc(&c->d_scale, (size_t)p->n_mat * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&c->d_drift, (size_t)p->n_steps * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->d_clk, 64);

@@ -758,9 +758,13 @@ __device__ __forceinline__ void grid_sum_finish(double (&v)[N], double* smem /*[
 // a workgroup's row is written as one contiguous piece; the strided reads here are served by the L2.
 // grid = ncol workgroups of 256 threads.  fix0: if >= 0, out[0] is overwritten with that value
 // (P_sum[0] = 2 N of market_data.cuh:76-78, done without the reference's write race).
+// stamps (may be nullptr): after its store every workgroup publishes `seq` in stamps[blockIdx.x] with system-scope release
+// order -- when `out` is pinned host memory the host can see a result the moment it lands instead of waiting for the
+// runtime to notice the end of the stream (hw_engine.hip, timed_sync).
 __global__ void finalize_columns_kernel(const double* __restrict__ partials, int nrows, int row_stride, int col_stride,
                                         const double* __restrict__ scale, double fix0,
-                                        double* __restrict__ out, int ncol)
+                                        double* __restrict__ out, int ncol,
+                                        unsigned long long* __restrict__ stamps = nullptr, unsigned long long seq = 0)
 {
     __shared__ double smem[256];
     const int k = blockIdx.x % ncol, group = blockIdx.x / ncol;
@@ -778,6 +782,10 @@ __global__ void finalize_columns_kernel(const double* __restrict__ partials, int
         if (scale) r *= scale[k];
         if (k == 0 && fix0 >= 0.0) r = fix0;
         out[(size_t)group * ncol + k] = r;
+        if (stamps != nullptr) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");             // system scope: the result before its stamp, as the host sees them
+            __hip_atomic_store(stamps + blockIdx.x, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

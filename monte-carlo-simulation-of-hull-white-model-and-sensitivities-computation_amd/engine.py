@@ -185,7 +185,7 @@ class HullWhiteEngine:
         r = self._request(n_pairs, seed, path_offset, S1, S2, K, sigma, drift_mode, stepper)
         out = np.zeros(5, np.float64)
         ms = C.c_float(0)
-        L.check(self.lib.hw_zbc_moments(self._ctx, C.byref(r), _dp(out), C.byref(ms)))
+        L.check(self.lib.hw_zbc_moments(self._ctx, C.byref(r), _dp(out), C.byref(ms) if return_ms else None))
         return (out, ms.value) if return_ms else out
 
     def enqueue_ZBC(self, d_out_ptr, n_pairs, seed, path_offset=0, S1=5.0, S2=10.0, K=None,
@@ -203,7 +203,7 @@ class HullWhiteEngine:
         out = np.zeros(5 * n_runs, np.float64)
         ms = C.c_float(0)
         L.check(self.lib.hw_zbc_moments_runs(self._ctx, C.byref(r), int(n_runs), int(seed_stride), _dp(out),
-                                             C.byref(ms)))
+                                             C.byref(ms) if return_ms else None))
         out = out.reshape(n_runs, 5)
         return (out, ms.value) if return_ms else out
 
@@ -216,7 +216,7 @@ class HullWhiteEngine:
         dm = (C.c_int32 * n)(*[int(m) for m in drift_modes])
         out = np.zeros(5 * n, np.float64)
         ms = C.c_float(0)
-        L.check(self.lib.hw_zbc_scenarios(self._ctx, C.byref(r), n, sg, dm, _dp(out), C.byref(ms)))
+        L.check(self.lib.hw_zbc_scenarios(self._ctx, C.byref(r), n, sg, dm, _dp(out), C.byref(ms) if return_ms else None))
         out = out.reshape(n, 5)
         return (out, ms.value) if return_ms else out
 
@@ -225,7 +225,7 @@ class HullWhiteEngine:
         out = np.zeros(self.params.n_mat, np.float64)
         ms = C.c_float(0)
         L.check(self.lib.hw_zcb_curve(self._ctx, int(n_pairs), int(seed), int(path_offset),
-                                      float(sigma), _dp(out), C.byref(ms)))
+                                      float(sigma), _dp(out), C.byref(ms) if return_ms else None))
         return (out, ms.value) if return_ms else out
 
     def enqueue_zcb(self, d_out_ptr, n_pairs, seed, path_offset=0, sigma=0.0, stream=None):
@@ -249,7 +249,7 @@ class HullWhiteEngine:
         L.check(self.lib.hw_vega_pathwise(self._ctx, int(n_paths), int(seed), int(path_offset),
                                           float(S1), float(S2),
                                           float(K_DEFAULT if K is None else K),
-                                          1 if antithetic else 0, _dp(out), C.byref(ms)))
+                                          1 if antithetic else 0, _dp(out), C.byref(ms) if return_ms else None))
         return (float(out[0]), ms.value) if return_ms else float(out[0])
 
     def simulate_sensitivity_runs(self, n_paths, seed, n_runs=20, seed_stride=982451653, path_offset=0, S1=5.0,
@@ -260,7 +260,7 @@ class HullWhiteEngine:
         L.check(self.lib.hw_vega_pathwise_runs(self._ctx, int(n_paths), int(seed), int(path_offset), float(S1),
                                                float(S2), float(K_DEFAULT if K is None else K),
                                                int(bool(antithetic)), int(n_runs), int(seed_stride), _dp(out),
-                                               C.byref(ms)))
+                                               C.byref(ms) if return_ms else None))
         return (out, ms.value) if return_ms else out
 
     def enqueue_sensitivity(self, d_out_ptr, n_paths, seed, path_offset=0, S1=5.0, S2=10.0, K=None,

@@ -8,7 +8,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/collect_$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
-step() { echo "== $1" >&2; shift; timeout -k 10 "$@" || { echo "step failed: rc=$?" >&2; exit 1; }; }
+exec 3>&1                             # the script's own stdout: step headers go there, not into the step's output file
+step() { echo "== $1" >&3; shift; timeout -k 10 "$@" || { echo "step failed: rc=$?" >&3; exit 1; }; }
 step "size scan zbc"  200 python tools/size_scan.py --kernel zbc --rounds 7 > "$OUT/size_scan_zbc.txt" 2>&1
 step "size scan zcb"  300 python tools/size_scan.py --kernel zcb --rounds 7 > "$OUT/size_scan_zcb.txt" 2>&1
 step "size scan vega" 200 python tools/size_scan.py --kernel vega --rounds 7 > "$OUT/size_scan_vega.txt" 2>&1
