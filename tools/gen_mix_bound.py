@@ -203,7 +203,7 @@ def census_of(lines):
     return c
 
 
-def generate():
+def generate(search=0):
     text = listing()
     p1 = production_loop(text, "zbc_superposed_kernelIfLi1ELi1E", 16)
     p2 = production_loop(text, "zbc_superposed_kernelIfLi1ELi2E", 32)
@@ -237,6 +237,8 @@ def generate():
                      ("TRANS_SIMPLE", lambda x: is_trans(x) or is_simple(x)), ("CVT_SIMPLE", lambda x: is_cvt(x) or is_simple(x)),
                      ("MAD_CVT", lambda x: is_mad(x) or is_cvt(x)), ("TRANS_CVT", lambda x: is_trans(x) or is_cvt(x))):
         variants[nm] = ([x for x in valu if pred(x)], 1)
+    if search:
+        return search_variants(valu, search, (is_mad, is_cvt, is_trans, is_simple))
     c1, c2 = census_of(variants["PROD1"][0]), census_of(variants["PROD2"][0])
     fh.write("#define MIX_CENSUS_PROD1_FULL %d\n#define MIX_CENSUS_PROD1_HALF %d\n#define MIX_CENSUS_PROD1_QUARTER %d\n"
              % (c1["full"], c1["half"], c1["quarter"]))
@@ -244,10 +246,69 @@ def generate():
              % (c2["full"], c2["half"], c2["quarter"]))
     for name, (lines, blocks) in variants.items():
         emit(name, lines, blocks, fh, census_of(lines))
+    full = {"PROD1", "PROD1_NOPRIO", "PROD2", "PROD2_NOPRIO", "GROUPED", "GROUPED_PRIO", "REAL1", "REAL2"}
+    fh.write("#define MIX_VARIANTS(X) \\\n" + " \\\n".join(
+        "    X(%s, %d, %d)" % (name, 0 if name.startswith("REAL") else 1, 1 if name in full else 0) for name in variants) + "\n")
+    return fh.getvalue()
+
+
+def search_variants(valu, n, preds):
+    """n random ORDERINGS and priority schemes of the production loop's 60 dependency-free instructions (any order is valid
+    once the dependencies are gone): the classes' instructions are dealt out in chunks of a random size per class, the
+    classes taken in a random cyclic order, and a random subset of the classes is issued at priority 1 (s_setprio at every
+    change, with or without the s_nop the production code puts behind it).  Fixed seed: the search is reproducible.  If one
+    of them ran faster than the production ordering, the 'bound' would not be one."""
+    import io
+    import random
+    rng = random.Random(20250605)
+    names = ("mad", "cvt", "trans", "simple")
+    pools = [[x for x in valu if p(x)] for p in preds]
+    fh = io.StringIO()
+    fh.write("// GENERATED by tools/gen_mix_bound.py --search %d (random orderings / priority schemes of PROD1's instructions) -- do not edit.\n\n" % n)
+    fh.write("#define MIX_CENSUS_PROD1_FULL 32\n#define MIX_CENSUS_PROD1_HALF 20\n#define MIX_CENSUS_PROD1_QUARTER 8\n\n")
+    listed = []
+    for k in range(n):
+        chunk = [rng.choice((1, 2, 4, 8, 16)), rng.choice((1, 2, 4)), rng.choice((1, 2, 4, 8)), rng.choice((1, 2, 4, 8, 16, 32))]
+        order = list(range(4))
+        rng.shuffle(order)
+        hi = [rng.random() < 0.5 for _ in range(4)]
+        nop = rng.random() < 0.5
+        left = [list(p) for p in pools]
+        seq = []
+        while any(left):
+            for c in order:
+                for _ in range(chunk[c]):
+                    if left[c]:
+                        seq.append((c, left[c].pop(0)))
+        lines, cur = [], None
+        use_prio = any(hi) and not all(hi)
+        for c, ins in seq:
+            if use_prio and hi[c] != cur:
+                lines.append("s_setprio %d" % (1 if hi[c] else 0))
+                if nop:
+                    lines.append("s_nop 0")
+                cur = hi[c]
+        # (the priority a trip ends on is the one the next trip starts on: a wave keeps it across the back edge)
+            lines.append(ins)
+        name = "S%03d" % k
+        desc = "order %s chunks %s prio1 {%s}%s" % ("-".join(names[c] for c in order), "/".join("%s %d" % (names[c], chunk[c]) for c in range(4)),
+                                                  ",".join(names[c] for c in range(4) if hi[c]) if use_prio else "none",
+                                                  " +s_nop" if (use_prio and nop) else "")
+        fh.write("// %s: %s\n" % (name, desc))
+        emit(name, lines, 1, fh, census_of(lines))
+        listed.append(name)
+    fh.write("#define MIX_VARIANTS(X) \\\n" + " \\\n".join("    X(%s, 1, 1)" % nm for nm in listed) + "\n")
     return fh.getvalue()
 
 
 def main():
+    if "--search" in sys.argv:
+        n = int(sys.argv[sys.argv.index("--search") + 1])
+        out = os.path.join(ROOT, "tools", "mix_search_body.inc")
+        with open(out, "w") as fh:
+            fh.write(generate(search=n))
+        print("wrote", out)
+        return
     text = generate()
     if "--check" in sys.argv:
         ok = os.path.exists(OUT) and open(OUT).read() == text

@@ -19,7 +19,10 @@
 #include <cstring>
 #include <string>
 #include <vector>
-#include "mix_bound_body.inc"
+#ifndef MIX_INC
+#define MIX_INC "mix_bound_body.inc"        // -DMIX_INC='"mix_search_body.inc"': the random-ordering search (gen_mix_bound.py --search N)
+#endif
+#include MIX_INC
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
@@ -67,25 +70,8 @@
         }                                                                                                             \
     }
 
-MIX_KERNEL(PROD1)
-MIX_KERNEL(PROD1_NOPRIO)
-MIX_KERNEL(PROD2)
-MIX_KERNEL(PROD2_NOPRIO)
-MIX_KERNEL(GROUPED)
-MIX_KERNEL(GROUPED_PRIO)
-MIX_KERNEL(EXCL)
-MIX_KERNEL(SIMPLE)
-MIX_KERNEL(REAL1)
-MIX_KERNEL(REAL2)
-MIX_KERNEL(MAD)
-MIX_KERNEL(TRANS)
-MIX_KERNEL(CVT)
-MIX_KERNEL(MAD_TRANS)
-MIX_KERNEL(MAD_SIMPLE)
-MIX_KERNEL(TRANS_SIMPLE)
-MIX_KERNEL(CVT_SIMPLE)
-MIX_KERNEL(MAD_CVT)
-MIX_KERNEL(TRANS_CVT)
+#define MIX_DEFINE(NAME, DF, FM) MIX_KERNEL(NAME)
+MIX_VARIANTS(MIX_DEFINE)
 
 typedef void (*Kern)(unsigned long long*, unsigned, unsigned, float);
 
@@ -96,31 +82,20 @@ int main(int argc, char** argv)
 {
     int budget = 300000;                                   // window in s_memrealtime ticks of 10 ns (3 ms)
     bool json = false;
+    int only_occ = 0;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--json")) json = true;
+        else if (!strcmp(argv[i], "--occ") && i + 1 < argc) only_occ = atoi(argv[++i]);
         else budget = atoi(argv[i]);
     }
     if (budget < 20000) budget = 20000;
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
-    const Variant vars[] = {
-        {"PROD1", mix_PROD1, MIX_BLOCKS_PROD1, true, true},
-        {"PROD1_NOPRIO", mix_PROD1_NOPRIO, MIX_BLOCKS_PROD1_NOPRIO, true, true},
-        {"PROD2", mix_PROD2, MIX_BLOCKS_PROD2, true, true},
-        {"PROD2_NOPRIO", mix_PROD2_NOPRIO, MIX_BLOCKS_PROD2_NOPRIO, true, true},
-        {"GROUPED", mix_GROUPED, MIX_BLOCKS_GROUPED, true, true},
-        {"GROUPED_PRIO", mix_GROUPED_PRIO, MIX_BLOCKS_GROUPED_PRIO, true, true},
-        {"EXCL", mix_EXCL, MIX_BLOCKS_EXCL, true, false},
-        {"SIMPLE", mix_SIMPLE, MIX_BLOCKS_SIMPLE, true, false},
-        {"REAL1", mix_REAL1, MIX_BLOCKS_REAL1, false, true},
-        {"REAL2", mix_REAL2, MIX_BLOCKS_REAL2, false, true},
-        {"MAD", mix_MAD, 1, true, false}, {"TRANS", mix_TRANS, 1, true, false}, {"CVT", mix_CVT, 1, true, false},
-        {"MAD_TRANS", mix_MAD_TRANS, 1, true, false}, {"MAD_SIMPLE", mix_MAD_SIMPLE, 1, true, false},
-        {"TRANS_SIMPLE", mix_TRANS_SIMPLE, 1, true, false}, {"CVT_SIMPLE", mix_CVT_SIMPLE, 1, true, false},
-        {"MAD_CVT", mix_MAD_CVT, 1, true, false}, {"TRANS_CVT", mix_TRANS_CVT, 1, true, false},
-    };
-    const int occs[] = {4, 6, 8};                          // waves per SIMD
+#define MIX_ROW(NAME, DF, FM) {#NAME, mix_##NAME, MIX_BLOCKS_##NAME, DF != 0, FM != 0},
+    const Variant vars[] = { MIX_VARIANTS(MIX_ROW) };
+    std::vector<int> occs = {4, 6, 8};                     // waves per SIMD
+    if (only_occ) occs.assign(1, only_occ);
     const size_t max_waves = (size_t)cus * 4 * 8;
     unsigned long long* d_out;
     CHECK(hipMalloc(&d_out, max_waves * 3 * sizeof(unsigned long long)));
@@ -143,7 +118,7 @@ int main(int argc, char** argv)
     };
     for (int i = 0; i < 60; i++) {
         const unsigned long long dl = deadline();
-        hipLaunchKernelGGL(mix_PROD1, dim3(cus * 3), dim3(512), 0, 0, d_out, (unsigned)dl, (unsigned)(dl >> 32), 0.3f);
+        hipLaunchKernelGGL(vars[0].k, dim3(cus * 3), dim3(512), 0, 0, d_out, (unsigned)dl, (unsigned)(dl >> 32), 0.3f);
     }
     CHECK(hipDeviceSynchronize());
     for (const Variant& v : vars)
