@@ -85,8 +85,8 @@ def test_bench_default_line_carries_the_side_measurements():
     assert d["q1_curve_gpu"]["value"] > 391.0                  # the reference's V100 figure for this kernel (README.md:9-12)
 
 
-@pytest.mark.parametrize("every", ["1", "0"])
-def test_bench_two_rank_strong_scaling_rehearsal(every):
+@pytest.mark.parametrize("every,regions", [("1", "2"), ("0", "2"), ("1", None)])
+def test_bench_two_rank_strong_scaling_rehearsal(every, regions):
     """N = 2 launched exactly as the driver does (torch.distributed.run, one process per rank), in rehearsal mode: both
     ranks on the one visible GPU, all-reduce over gloo.  Not a measurement -- it pins the multi-rank control flow of
     the DEFAULT mode: strong scaling of one 2^k-pair pricing call (BASELINE configs[3] at k = 24; k = 18 here), sharded
@@ -97,7 +97,8 @@ def test_bench_two_rank_strong_scaling_rehearsal(every):
     e = dict(os.environ, HWMC_BENCH_REHEARSAL="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--spinup-ms", "50", "--regions", "2",
+                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--spinup-ms", "50",
+                        *(["--regions", regions] if regions else []),   # None: the driver's form -- the region count is agreed between the ranks
                         "--total-log2", "18", "--allreduce-every", every],
                        capture_output=True, text=True, timeout=400, env=e, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -105,6 +106,9 @@ def test_bench_two_rank_strong_scaling_rehearsal(every):
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert CONTRACT_KEYS <= set(d) and d["n_gpus"] == 2 and "rehearsal" in d
+    if regions is None:
+        assert 7 <= d["value_spread"]["timed_regions"] <= 400 and d["timed_region_s"] > 0
+        assert len(d["value_spread"]["region_ms"]) == d["value_spread"]["timed_regions"]
     assert d["scaling"] == "strong"
     assert d["config"]["pairs_per_step"] == 1 << 18 and d["config"]["pairs_per_gpu"] == 1 << 17
     assert d["config"]["effective_paths"] == 2 * (1 << 18)
