@@ -88,3 +88,38 @@ def test_more_table_uploads_in_flight_than_staging_slots(hwmc_mod):
 
 # (what a caller may do with a stream AFTER a call -- destroy it, before or after the context -- is exercised by
 # tests/test_gpu_hazards.py, one child process per case)
+
+
+def test_polled_completion_equals_stream_synchronisation(hwmc_mod, monkeypatch):
+    """A synchronous call that is not asked for the kernel time returns when the completion stamps of ITS results have
+    landed in the pinned host buffer (include/hw_mc.h); HWMC_SPIN_WAIT=0 (read by hw_create) waits for the stream instead.
+    Same kernels, so the sums must be bit-identical: small launches (the stamps arrive while the host polls), launches
+    longer than the 300 us polling window (the fallback), every synchronous entry point, many calls in a row (a stale stamp
+    of an earlier call must never be taken for the current one), and interleaved with calls that DO ask for the time."""
+    p = hwmc_mod.default_params("readme")
+    P, f = hwmc_mod.analytic_curve(p)
+    polled = hwmc_mod.HullWhiteEngine(p, device=0)
+    monkeypatch.setenv("HWMC_SPIN_WAIT", "0")
+    waited = hwmc_mod.HullWhiteEngine(p, device=0)
+    monkeypatch.delenv("HWMC_SPIN_WAIT")
+    try:
+        for e in (polled, waited):
+            e.load_market_data(P, f)
+        for n in (1, 777, 1 << 14, 1 << 20, 1 << 23):                        # 2^23 pairs: 1.4 ms, far beyond the polling window
+            a, b = polled.simulate_ZBC_control_variate(n, 5), waited.simulate_ZBC_control_variate(n, 5)
+            assert np.array_equal(a, b) and a[0] > 0, n
+        for i in range(300):                                                 # back to back, alternating sizes: no stale stamps
+            n = 4096 if i % 2 else 300
+            assert np.array_equal(polled.simulate_ZBC_control_variate(n, 100 + i), waited.simulate_ZBC_control_variate(n, 100 + i)), i
+        assert np.array_equal(polled.simulate_zcb(50_000, 3), waited.simulate_zcb(50_000, 3))
+        assert polled.simulate_sensitivity(1 << 16, 9) == waited.simulate_sensitivity(1 << 16, 9)
+        assert np.array_equal(polled.simulate_ZBC_runs(30_000, 1234, n_runs=20), waited.simulate_ZBC_runs(30_000, 1234, n_runs=20))
+        assert np.array_equal(polled.simulate_ZBC_scenarios(1 << 15, 7, [0.099, 0.1, 0.101], [1, 0, 1]),
+                              waited.simulate_ZBC_scenarios(1 << 15, 7, [0.099, 0.1, 0.101], [1, 0, 1]))
+        assert np.array_equal(polled.simulate_sensitivity_runs(20_000, 4, n_runs=20), waited.simulate_sensitivity_runs(20_000, 4, n_runs=20))
+        for i in range(20):                                                  # with and without the event pair, mixed
+            s, ms = polled.simulate_ZBC_control_variate(9999, i, return_ms=True)
+            assert ms > 0 and np.array_equal(s, polled.simulate_ZBC_control_variate(9999, i))
+    finally:
+        polled.close()
+        waited.close()
