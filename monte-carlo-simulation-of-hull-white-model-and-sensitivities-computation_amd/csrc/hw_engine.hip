@@ -27,6 +27,7 @@
 #include "../../include/hw_mc.h"
 #include "hw_kernels.hpp"
 #include "hw_model.hpp"
+#include "hw_stream_guard.hpp"
 
 namespace {
 
@@ -115,17 +116,10 @@ struct hw_ctx {
     int prof_used = 0, prof_cap = 0;
     // The workspaces above are reused by every launch of the context, in stream order.  A call that arrives on a
     // DIFFERENT stream than the previous one first makes its stream wait (on the device) for everything the context
-    // has enqueued so far: on_stream().  RULE: the library never hands a caller's stream handle to HIP after the call
-    // that received it has returned (the caller may destroy the stream any time after that).  So `tail_stream` is
-    // only ever COMPARED; what the next call waits on is `ev_tail`, an event of the context, recorded on a caller's
-    // stream at the END of the call that used it (seal_stream), while the stream is certainly alive.  For streams the
-    // library owns itself -- the context's own, a pipe's candidates -- the record is deferred to the moment another
-    // stream actually shows up (use_stream): calls that stay on one owned stream pay nothing.
-    hipStream_t tail_stream = nullptr;    // stream of the context's latest enqueue: a VALUE to compare, not a handle to use
-    bool have_tail = false;
-    bool tail_recorded = false;           // ev_tail covers everything this context has enqueued so far
-    hipEvent_t ev_tail = nullptr;
-    bool streams_owned = false;           // hw_pipe: every stream it passes in is the pipe's own and outlives the context
+    // has enqueued so far, and the library never hands a caller's stream handle to HIP after the call that received it
+    // has returned: hw_stream_guard.hpp (the state machine, checked on the CPU with a mock) + on_stream() below.
+    hw::StreamGuard<hipStream_t> guard;
+    hipEvent_t ev_tail = nullptr;         // "everything this context has enqueued so far" (see the guard)
     // workspaces outgrown while launches may still be reading them: freed at the next host synchronisation / destroy
     std::vector<void*> retired;
     // pinned staging ring for the small host->device uploads (drift table of the REFERENCE stepper, per-maturity
@@ -163,33 +157,32 @@ void free_retired(hw_ctx* c)          // caller guarantees that nothing enqueued
     c->retired.clear();
 }
 
-// Stream-order guard of the per-context workspaces (d_partials, d_ticket, d_drift, d_scale): see hw_ctx.
-inline bool stream_is_owned(const hw_ctx* c, hipStream_t st) { return st == c->stream || c->streams_owned; }
+// Stream-order guard of the per-context workspaces (d_partials, d_ticket, d_drift, d_scale): hw_stream_guard.hpp.
+struct GuardOps {
+    hw_ctx* c;
+    hipError_t err = hipSuccess;
+    const char* what = "";
+    int record(hipStream_t s) { what = "hipEventRecord"; err = hipEventRecord(c->ev_tail, s); return err == hipSuccess ? 0 : 1; }
+    int wait(hipStream_t s) { what = "hipStreamWaitEvent"; err = hipStreamWaitEvent(s, c->ev_tail, 0); return err == hipSuccess ? 0 : 1; }
+};
+
+int guard_result(int r, const GuardOps& ops)
+{
+    if (r == 0) return HW_OK;
+    if (r == hw::kGuardInternalError) return fail(HW_E_HIP, "internal: unsealed caller stream in the context's stream guard");
+    return fail(HW_E_HIP, "HIP error [%s] in the stream guard: %s", ops.what, hipGetErrorString(ops.err));
+}
 
 int use_stream(hw_ctx* c, hipStream_t st)
 {
-    if (c->have_tail && c->tail_stream != st) {
-        if (!c->tail_recorded) {
-            // only reachable for a stream the library owns (seal_stream records every other one before its call returns)
-            if (!stream_is_owned(c, c->tail_stream)) return fail(HW_E_HIP, "internal: unsealed caller stream in the context's stream guard");
-            HIP_TRY(hipEventRecord(c->ev_tail, c->tail_stream));
-            c->tail_recorded = true;
-        }
-        HIP_TRY(hipStreamWaitEvent(st, c->ev_tail, 0));
-    }
-    c->tail_recorded = false;             // new work is about to follow on st: ev_tail (if recorded) no longer covers it
-    c->tail_stream = st;
-    c->have_tail = true;
-    return HW_OK;
+    GuardOps ops{c};
+    return guard_result(c->guard.enter(ops, st), ops);
 }
 
-// End of an enqueue on `st`: if it is a caller's stream, record the context's tail event on it NOW.
 int seal_stream(hw_ctx* c, hipStream_t st)
 {
-    if (!c->have_tail || c->tail_stream != st || c->tail_recorded || stream_is_owned(c, st)) return HW_OK;
-    HIP_TRY(hipEventRecord(c->ev_tail, st));
-    c->tail_recorded = true;
-    return HW_OK;
+    GuardOps ops{c};
+    return guard_result(c->guard.leave(ops, st), ops);
 }
 
 // Every enqueue of a context runs inside this bracket (whatever it returns, the stream is sealed).
@@ -723,6 +716,7 @@ int hw_create(const hw_params* p, int device, hw_ctx** out)
     c->device = device;
     hipError_t e = hipGetDeviceProperties(&c->prop, device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) c->guard.set_own_stream(c->stream);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming);
@@ -762,9 +756,11 @@ void hw_destroy(hw_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     // work the context left on another stream: wait on the context's OWN event (recorded when that call ended), never on
     // the caller's stream handle, which may be gone; a pipe's streams are the library's and still alive here
-    if (c->have_tail && c->tail_stream != c->stream) {
-        if (c->tail_recorded) (void)hipEventSynchronize(c->ev_tail);
-        else if (c->streams_owned) (void)hipStreamSynchronize(c->tail_stream);
+    {
+        hipStream_t other = nullptr;
+        const auto pend = c->guard.pending(&other);
+        if (pend == hw::StreamGuard<hipStream_t>::Pending::TailEvent) (void)hipEventSynchronize(c->ev_tail);
+        else if (pend == hw::StreamGuard<hipStream_t>::Pending::OwnedStream) (void)hipStreamSynchronize(other);
     }
     free_retired(c);
     for (hw_ctx::Stage& sl : c->stage) {
@@ -1378,7 +1374,7 @@ int hw_pipe_create(const hw_params* p, int device, int32_t n_queues, hw_pipe** o
         hw_ctx* c = nullptr;
         const int rc = hw_create(p, q == 0 ? device : pp->device, &c);
         if (rc) { hw_pipe_destroy(pp); return rc; }
-        c->streams_owned = true;                          // the pipe's candidate streams are destroyed after its contexts
+        c->guard.set_all_streams_owned(true);             // the pipe's candidate streams are destroyed after its contexts
         pp->ctx.push_back(c);
         pp->device = c->device;                            // (device < 0: every queue on the device the first context picked)
     }

@@ -64,3 +64,20 @@ def test_integration_md_call_shapes_compile_and_link(tmp_path, hwmc_mod):
                            os.path.join(ROOT, "tests", "cpp", "integration_shapes.cpp"), "-o", exe,
                            "-L" + PKG, "-lhw_hip", "-Wl,-rpath," + PKG])
     assert os.path.exists(exe)
+
+
+def test_stream_guard_state_machine_against_a_mock_runtime(tmp_path):
+    """The guard that orders a context's launches across streams (csrc/hw_stream_guard.hpp) run against a mock of HIP's
+    stream/event semantics with caller streams created and destroyed at random (tests/cpp/stream_guard_probe.cpp):
+    every enqueue ordered behind all earlier ones, no record/wait ever on a dead stream, a pipe's contexts record only at
+    switches -- and round 2's lazy scheme, on the same schedule, does touch dead streams (the use-after-free behind
+    GPUTEST_r02.json's SIGSEGV)."""
+    exe = str(tmp_path / "stream_guard_probe")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(PKG, "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", "stream_guard_probe.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["order_violations"] == 0 and d["calls"] > 150_000 and d["calls_on_caller_streams"] > 30_000 and d["switches"] > 100_000
+    assert d["lazy_scheme_dead_stream_uses"] > 0
+    assert "0 uses of a dead stream" in r.stdout and "LIFETIME violated" not in r.stdout
