@@ -5,7 +5,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libhw_hip.so")
-SOURCES = ["hw_engine.hip", "hw_kernels.hpp", "hw_model.hpp", "hw_stream_guard.hpp"]
+SOURCES = ["hw_engine.hip", "hw_kernels.hpp", "hw_model.hpp", "hw_stream_guard.hpp", "hw_fleet.hpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wshadow", "-fno-slp-vectorize", "-fPIC", "-shared"]
 
 

@@ -28,6 +28,7 @@
 #include "hw_kernels.hpp"
 #include "hw_model.hpp"
 #include "hw_stream_guard.hpp"
+#include "hw_fleet.hpp"
 
 namespace {
 
@@ -1539,29 +1540,14 @@ struct hw_comm {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    // workers
-    std::vector<std::thread> workers;
-    std::mutex mu;
-    std::condition_variable cv_job, cv_done;
-    std::atomic<uint64_t> generation{0};
-    std::atomic<int> pending{0};
-    bool quit = false;
-    const std::function<int(int)>* job = nullptr;
-    std::vector<int> rc;
-    std::vector<std::string> err;
+    // G persistent worker threads + the two-phase job protocol (rendezvous between a device's own work and the collective,
+    // abort for failures inside the collective): hw_fleet.hpp, checked on the CPU under ThreadSanitizer with a mock collective
+    hw::Fleet fleet;
     // HW_COMM_HOST_SUM: no RCCL; every worker brings its shard's sums to its slot here and the caller adds the slots
     // in rank order (deterministic).  Contexts may then share a device: the threaded dispatch can be rehearsed, G > 1,
     // on a box with one GPU.
     bool host_sum = false;
     std::vector<double> host_slots;        // [G][kOutCap]
-    // Two-phase job (comm_run): phase 1 = everything that can fail on ONE device (geometry, workspace growth, table
-    // upload, kernel launches), no collective; the workers then meet here and enter phase 2 (the all-reduce) only if
-    // EVERY rank got through phase 1 -- a rank that failed alone would leave the others waiting in the collective.
-    std::atomic<int> arrived{0}, phase1_failed{0};
-    // A failure AFTER the rendezvous (the collective itself, the stream synchronisation behind it) cannot be undone
-    // rank by rank: the failing worker aborts every communicator (ncclCommAbort releases ranks blocked in the
-    // collective) and the fleet refuses further calls.
-    std::atomic<bool> broken{false};
     // failure injection for the rehearsal tests: HWMC_COMM_INJECT_FAIL=rank:phase[:count], read by hw_comm_create*
     int inject_rank = -1, inject_phase = 0;
     std::atomic<int> inject_left{0};
@@ -1575,59 +1561,14 @@ static void comm_shard(int64_t n, int g, int G, int64_t* off, int64_t* cnt)
     *cnt = base + (g < rem ? 1 : 0);
 }
 
-static void comm_worker(hw_comm* cm, int g)
+// run job on every worker, wait for all of them; the first failing rank's code and text reach the caller
+static int comm_dispatch(hw_comm* cm, const hw::Fleet::Job& job)
 {
-    (void)hipSetDevice(cm->ctx[g]->device);
-    uint64_t seen = 0;
-    for (;;) {
-        // hybrid wait: spin ~100 us (back-to-back pricing calls never pay a futex wake-up), then sleep
-        bool got = false;
-        const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(100);
-        while (std::chrono::steady_clock::now() < spin_until) {
-            if (cm->generation.load(std::memory_order_acquire) != seen) { got = true; break; }
-            __builtin_ia32_pause();
-        }
-        if (!got) {
-            std::unique_lock<std::mutex> lk(cm->mu);
-            cm->cv_job.wait(lk, [&] { return cm->quit || cm->generation.load(std::memory_order_acquire) != seen; });
-            if (cm->quit) return;
-        }
-        {
-            std::lock_guard<std::mutex> lk(cm->mu);      // (job and quit are written under the mutex)
-            if (cm->quit) return;
-        }
-        seen = cm->generation.load(std::memory_order_acquire);
-        const int r = (*cm->job)(g);
-        cm->rc[g] = r;
-        cm->err[g] = r ? g_err : std::string();         // hw_last_error() is per thread: hand the text to the caller's
-        if (cm->pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-            std::lock_guard<std::mutex> lk(cm->mu);
-            cm->cv_done.notify_one();
-        }
-    }
-}
-
-// run job(g) on every worker, wait for all of them; first failure wins
-static int comm_dispatch(hw_comm* cm, const std::function<int(int)>& job)
-{
-    const int G = (int)cm->ctx.size();
-    {
-        std::lock_guard<std::mutex> lk(cm->mu);
-        cm->job = &job;
-        cm->arrived.store(0, std::memory_order_relaxed);          // (every worker of the previous job has returned)
-        cm->phase1_failed.store(0, std::memory_order_relaxed);
-        cm->pending.store(G, std::memory_order_release);
-        cm->generation.fetch_add(1, std::memory_order_acq_rel);
-    }
-    cm->cv_job.notify_all();
-    {
-        std::unique_lock<std::mutex> lk(cm->mu);
-        cm->cv_done.wait(lk, [&] { return cm->pending.load(std::memory_order_acquire) == 0; });
-        cm->job = nullptr;
-    }
-    for (int g = 0; g < G; g++)
-        if (cm->rc[g] != HW_OK) return fail(cm->rc[g], "device %d: %s", cm->ctx[g]->device, cm->err[g].c_str());
-    return HW_OK;
+    int rc = HW_OK;
+    std::string text;
+    const int g = cm->fleet.dispatch(job, &rc, &text);
+    if (g < 0) return HW_OK;
+    return fail(rc, "device %d: %s", cm->ctx[g]->device, text.c_str());
 }
 
 static bool comm_inject(hw_comm* cm, int g, int phase)
@@ -1639,7 +1580,7 @@ static bool comm_inject(hw_comm* cm, int g, int phase)
 // release every rank that may be blocked in a collective: called once, by the first worker that fails in phase 2
 static void comm_abort_all(hw_comm* cm)
 {
-    if (cm->broken.exchange(true, std::memory_order_acq_rel)) return;
+    if (!cm->fleet.mark_broken()) return;
     int cur = 0;
     (void)hipGetDevice(&cur);
     for (size_t i = 0; i < cm->comm.size(); i++) {
@@ -1656,24 +1597,19 @@ template <typename F>
 static int comm_run(hw_comm* cm, int64_t n_units, int count_out, double* out, float* wall_ms, F enqueue)
 {
     if (count_out > kOutCap) return fail(HW_E_INVALID, "too many outputs");
-    if (cm->broken.load(std::memory_order_acquire))
+    if (cm->fleet.broken())
         return fail(HW_E_HIP, "this communicator was aborted after a device failed inside a collective: destroy it and create a new one");
     const int G = (int)cm->ctx.size();
     const auto t0 = std::chrono::steady_clock::now();
-    const std::function<int(int)> job = [&](int g) -> int {
+    const hw::Fleet::Job job = [&](int g, std::string* text) -> int {
         hw_ctx* c = cm->ctx[g];
         int64_t off, cnt;
         comm_shard(n_units, g, G, &off, &cnt);
         // ---- phase 1: this device's kernels (the only part that can fail on one rank alone)
         int rc = comm_inject(cm, g, 1) ? fail(HW_E_HIP, "injected failure on rank %d before the collective (HWMC_COMM_INJECT_FAIL)", g)
                                        : enqueue(g, off, cnt, cm->host_sum ? c->h_out_dev : c->d_out, c->stream);
-        if (rc) cm->phase1_failed.fetch_add(1, std::memory_order_release);
-        cm->arrived.fetch_add(1, std::memory_order_acq_rel);
-        for (unsigned spins = 0; cm->arrived.load(std::memory_order_acquire) < G; spins++) {     // every worker runs this job: they all arrive
-            __builtin_ia32_pause();
-            if ((spins & 1023) == 1023) std::this_thread::yield();
-        }
-        if (cm->phase1_failed.load(std::memory_order_acquire) > 0) {
+        if (rc) *text = g_err;                                  // hw_last_error() is per thread: hand the text to the caller's
+        if (!cm->fleet.rendezvous(rc)) {
             // all or nothing: NOBODY enters the collective.  Drain what this device was given and report; the healthy ranks
             // return HW_OK and comm_dispatch hands the failing rank's text to the caller.
             (void)hipStreamSynchronize(c->stream);
@@ -1697,15 +1633,16 @@ static int comm_run(hw_comm* cm, int64_t n_units, int count_out, double* out, fl
         }
         if (rc == HW_OK && e != hipSuccess) rc = fail(HW_E_HIP, "HIP error behind the collective: %s", hipGetErrorString(e));
         if (rc != HW_OK) {
+            *text = g_err;
             if (!cm->host_sum) comm_abort_all(cm);             // the other ranks may be blocked in the all-reduce: release them
             return rc;
         }
-        if (cm->broken.load(std::memory_order_acquire)) return HW_OK;     // released by a peer's abort: its error is the one reported
+        if (cm->fleet.broken()) return HW_OK;                   // released by a peer's abort: its error is the one reported
         free_retired(c);
         return HW_OK;
     };
     int rc = comm_dispatch(cm, job);
-    if (rc == HW_OK && cm->broken.load(std::memory_order_acquire))
+    if (rc == HW_OK && cm->fleet.broken())
         rc = fail(HW_E_HIP, "a device failed inside the collective; the communicator was aborted");
     if (rc == HW_OK && cm->host_sum)
         for (int k = 0; k < count_out; k++) {
@@ -1759,9 +1696,7 @@ int hw_comm_create_ex(int32_t n, hw_ctx* const* ctxs, int32_t flags, hw_comm** o
         }
         cm->host_sum = true;
         cm->host_slots.assign((size_t)n * kOutCap, 0.0);
-        cm->rc.assign(n, 0);
-        cm->err.assign(n, std::string());
-        for (int g = 0; g < n; g++) cm->workers.emplace_back(comm_worker, cm, g);
+        cm->fleet.start(n, [cm](int g) { (void)hipSetDevice(cm->ctx[g]->device); });
         *out = cm;
         return HW_OK;
     }
@@ -1793,9 +1728,7 @@ int hw_comm_create_ex(int32_t n, hw_ctx* const* ctxs, int32_t flags, hw_comm** o
         delete cm;
         return fail(HW_E_HIP, "ncclCommInitAll: %s", msg);
     }
-    cm->rc.assign(n, 0);
-    cm->err.assign(n, std::string());
-    for (int g = 0; g < n; g++) cm->workers.emplace_back(comm_worker, cm, g);
+    cm->fleet.start(n, [cm](int g) { (void)hipSetDevice(cm->ctx[g]->device); });
     *out = cm;
     return HW_OK;
 }
@@ -1803,15 +1736,9 @@ int hw_comm_create_ex(int32_t n, hw_ctx* const* ctxs, int32_t flags, hw_comm** o
 void hw_comm_destroy(hw_comm* cm)
 {
     if (!cm) return;
-    {
-        std::lock_guard<std::mutex> lk(cm->mu);
-        cm->quit = true;
-        cm->generation.fetch_add(1, std::memory_order_acq_rel);
-    }
-    cm->cv_job.notify_all();
-    for (std::thread& t : cm->workers) t.join();
+    cm->fleet.stop();
     for (size_t i = 0; i < cm->comm.size(); i++) {      // (no communicators in HW_COMM_HOST_SUM mode)
-        if (cm->broken.load()) break;                    // ncclCommAbort has already released them
+        if (cm->fleet.broken()) break;                   // ncclCommAbort has already released them
         (void)hipSetDevice(cm->ctx[i]->device);
         (void)cm->CommDestroy(cm->comm[i]);
     }

@@ -81,3 +81,20 @@ def test_stream_guard_state_machine_against_a_mock_runtime(tmp_path):
     assert d["order_violations"] == 0 and d["calls"] > 150_000 and d["calls_on_caller_streams"] > 30_000 and d["switches"] > 100_000
     assert d["lazy_scheme_dead_stream_uses"] > 0
     assert "0 uses of a dead stream" in r.stdout and "LIFETIME violated" not in r.stdout
+
+
+def test_fleet_two_phase_protocol_against_a_mock_collective(tmp_path):
+    """hw_comm_*'s host machinery (csrc/hw_fleet.hpp: persistent workers, rendezvous between a device's own work and the
+    collective, abort for failures inside it) with 1, 2, 3 and 8 workers against a mock all-reduce that -- like the real
+    one -- does not return until every rank has entered it (tests/cpp/fleet_probe.cpp): no rank enters the collective unless
+    all ranks got through phase 1, a phase-1 failure names its rank and leaves the fleet usable, a phase-2 failure aborts
+    exactly once and releases everybody, nothing ever waits longer than the watchdog.  The multi-GPU path has never run on
+    more than one device (no multi-GPU box): this is the part of it that does not need one."""
+    exe = str(tmp_path / "fleet_probe")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-pthread", "-I", os.path.join(PKG, "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", "fleet_probe.cpp"), "-o", exe])
+    r = subprocess.run([exe, "2000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["wrong"] == 0 and d["slow_dispatches"] == 0 and d["checks"] > 15_000 and d["phase1_failures"] > 1_500
+    assert d["workers_bound"] == 1 + 2 + 3 + 8

@@ -68,3 +68,15 @@ def test_host_logic_is_clean_under_asan_and_ubsan(tmp_path, hwmc_mod):
     stdout = _run(exe, str(tmp_path), env=env)
     d = json.loads([l for l in stdout.splitlines() if l.startswith("{")][0])
     assert d["shards"] == [[0, 334], [334, 334], [668, 333]] and d["theta_max_err"] < 0.01
+
+
+def test_fleet_protocol_is_clean_under_thread_sanitizer(tmp_path):
+    """The worker threads, the job hand-over (spin, then condition variable), the rendezvous and the abort flag of
+    csrc/hw_fleet.hpp under ThreadSanitizer, same probe as tests/test_host_cpp.py (fewer jobs: TSan is slow)."""
+    exe = str(tmp_path / "fleet_probe_tsan")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", "-I", os.path.join(PKG, "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", "fleet_probe.cpp"), "-o", exe])
+    r = subprocess.run([exe, "400"], capture_output=True, text=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr and "ThreadSanitizer" not in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["wrong"] == 0 and d["slow_dispatches"] == 0
