@@ -5,6 +5,8 @@ loop's instruction mix (bench.py `valu`).
 
     python tools/gen_mix_bound.py            # compiles the engine's device listing with the production flags, rewrites the .inc
     python tools/gen_mix_bound.py --check    # exit 1 if the committed .inc is not what the current sources generate
+    python tools/gen_mix_bound.py --search 96   # tools/mix_search_body.inc (NOT committed: 7 500 generated lines, fixed seed):
+                                                # hipcc ... -DMIX_INC='"mix_search_body.inc"' tools/mix_bound.hip -o tools/bin/mix_search
 
 How a dependency is removed: every VALU instruction keeps its opcode, encoding (e32/e64), modifiers, literal constants and
 the CLASS of every operand (VGPR / SGPR / literal), in the production order, between the production's own s_setprio /
