@@ -692,6 +692,55 @@ def test_full_size_properties_of_the_multi_gpu_shares(setup, hwmc_mod):
     assert v32 == pytest.approx(v64, rel=REL_F32) and v64 == pytest.approx(0.230244, abs=1e-3)
 
 
+def test_configs_3_and_4_whole_on_one_gpu(setup, hwmc_mod):
+    """BASELINE configs[3] (Q2b, 2^24 pairs, 8 GPUs, all-reduce of the moments) and configs[4] (2^26 pairs x 4000-step grid,
+    f32 vs f64, 8 GPUs) at their FULL path counts -- on the one GPU this suite has: the sample set depends only on
+    (seed, global pair id), so what eight devices would compute is, shard by shard, what eight calls with the shards'
+    offsets compute here, and the all-reduce is a sum of eight 5-vectors.  Checked: the eight shard calls add up to the
+    whole-batch call (1e-13); the in-process fleet with EIGHT worker threads (HW_COMM_HOST_SUM: the contexts share the
+    device, the library adds the shards in rank order) returns exactly that sum, bit for bit; the price sits within 4 SE of
+    the closed form at 2^25 / 2^27 paths (SE 3.5e-6 / 1.7e-6: a bias of 1e-5 would show); float and double steppers agree on
+    the same draws at the stress size.  No multi-GPU box has been available: this is the arithmetic of those two
+    configurations without the xGMI hop."""
+    exact = 0.03544557                                                             # Jamshidian, readme profile
+    e, _, P, f = setup("readme")
+    n, G = 1 << 24, 8
+    whole = e.simulate_ZBC_control_variate(n, 20240613)
+    shards = [e.simulate_ZBC_control_variate(n // G, 20240613, path_offset=g * (n // G)) for g in range(G)]
+    in_rank_order = np.zeros(5)
+    for sh in shards:
+        in_rank_order = in_rank_order + sh
+    np.testing.assert_allclose(whole, in_rank_order, rtol=1e-13)
+    p = hwmc_mod.default_params("readme")
+    engines = [hwmc_mod.HullWhiteEngine(p, device=0) for _ in range(G)]
+    try:
+        for x in engines:
+            x.load_market_data(P, f)
+        with hwmc_mod.HullWhiteFleet(engines, host_sum=True) as fleet:
+            got, ms = fleet.simulate_ZBC_control_variate(n, 20240613, return_ms=True)
+            assert np.array_equal(got, in_rank_order) and ms > 0
+            runs = fleet.simulate_ZBC_runs(1 << 21, 1234, n_runs=20, seed_stride=12345)        # the 20-run validation, sharded
+            np.testing.assert_allclose(runs, e.simulate_ZBC_runs(1 << 21, 1234, n_runs=20, seed_stride=12345), rtol=1e-13)
+    finally:
+        for x in engines:
+            x.close()
+    r = hwmc_mod.cv_price(whole, 2 * n, float(P[-1]))
+    assert abs(r["price"] - exact) < 4 * r["ci95_halfwidth"] / 1.96, (r["price"], r["ci95_halfwidth"])
+    assert r["beta"] == pytest.approx(0.166309, abs=3e-4) and r["rho"] == pytest.approx(0.6738, abs=5e-4)
+    # configs[4]: the stress size, both precisions
+    n5 = 1 << 26
+    e32, _, P4, _ = setup("readme", "f32", 4000)
+    e64, _, _, _ = setup("readme", "f64", 4000)
+    s32 = e32.simulate_ZBC_control_variate(n5, 99)
+    s64 = e64.simulate_ZBC_control_variate(n5, 99)
+    np.testing.assert_allclose(s32, s64, rtol=REL_F32)
+    eighth = sum(e32.simulate_ZBC_control_variate(n5 // G, 99, path_offset=g * (n5 // G)) for g in range(G))
+    np.testing.assert_allclose(s32, eighth, rtol=1e-13)
+    r32, r64 = (hwmc_mod.cv_price(x, 2 * n5, float(P4[-1])) for x in (s32, s64))
+    assert r32["price"] == pytest.approx(r64["price"], rel=REL_F32) and r32["beta"] == pytest.approx(r64["beta"], rel=REL_F32)
+    assert abs(r64["price"] - exact) < 4 * r64["ci95_halfwidth"] / 1.96 + 2e-6, (r64["price"], r64["ci95_halfwidth"])   # + trapezoid bias at dt = 0.0025
+
+
 def test_weak_mean_reversion_falls_back_to_the_per_step_form(hwmc_mod, oracle_mod):
     """The float (y, W) form of the time loop divides by 1 - e and is used only while (1 - e) sqrt(steps) >= 0.05
     (ou_walk).  Away from the reference's a = 1 every float32 implementation -- the float32 oracle included -- sits
