@@ -193,3 +193,102 @@ def test_oracle_edge_cases(oracle_mod, hwmc_mod):
     np.testing.assert_allclose(whole, parts, rtol=1e-13)     # sharding by path_offset
     one = o.zbc_moments(P, f, 1000, 3, n_threads=1)
     np.testing.assert_allclose(whole, one, rtol=1e-13)       # thread count does not matter
+
+
+# ---- a SECOND, independent restatement of the per-path bodies (NumPy float32, written from the reference source, not from
+# ---- oracle/): a transcription mistake in the C oracle would have to be made twice, in two languages, to go unnoticed -------
+def _np_normals(o, seed, n_pairs, n_steps):
+    """g[pair, step] from the pinned RNG layer (Philox + Box-Muller: tests above): step i uses component i & 3 of block i >> 2."""
+    g = np.zeros((n_pairs, n_steps), np.float32)
+    for pid in range(n_pairs):
+        for b in range((n_steps + 3) // 4):
+            g[pid, 4 * b:4 * b + 4] = o.normal4(seed, pid, b)[: n_steps - 4 * b]
+    return g
+
+
+def _np_fma(a, b, c):
+    """__fmaf_rn(a, b, c) for float32 arrays: the product of two floats is exact in double; one rounding to double, one to float."""
+    return (a.astype(np.float64) * np.float64(b) + c.astype(np.float64)).astype(np.float32)
+
+
+def _np_step(r, integral, drift, sig_g, e, dt):
+    """evolve_hull_white_step, common.cuh:237-244."""
+    f = np.float32
+    r_next = _np_fma(r, e, (f(drift) + sig_g).astype(np.float32))
+    integral = (integral + (f(0.5) * (r + r_next)).astype(np.float32) * f(dt)).astype(np.float32)
+    return r_next, integral
+
+
+def _np_interp(data, T, spacing):
+    """interpolate, common.cuh:187-196."""
+    f = np.float32
+    idx = int(f(T) / f(spacing))
+    if idx >= len(data) - 1:
+        return f(data[-1])
+    t0 = f(idx) * f(spacing)
+    alpha = (f(T) - t0) / f(spacing)
+    return f(f(data[idx]) * (f(1) - alpha) + f(data[idx + 1]) * alpha)
+
+
+@pytest.mark.parametrize("profile", ["head", "readme"])
+def test_second_restatement_of_the_zbc_body_in_numpy(oracle_mod, hwmc_mod, profile):
+    """simulate_ZBC_control_variate (common.cuh:286-362) with B_func / compute_A_HW / compute_P_HW (common.cuh:180-225),
+    statement by statement in NumPy float32 on 192 pairs, against the C oracle's five sums: 2e-6 relative (NumPy's float32
+    exp is not glibc's expf: up to an ulp per call)."""
+    f = np.float32
+    p = hwmc_mod.default_params(profile)
+    P, fw = hwmc_mod.analytic_curve(p)
+    o = oracle_mod.Oracle(profile)
+    n, seed, S1, S2, K = 192, 20240613, f(5.0), f(10.0), f(np.exp(f(-0.1)))
+    dt, _, e, sig_st = (f(x) for x in o.constants()[:4])
+    drift, _ = o.tables()
+    a, sigma, r0, spacing = f(1.0), f(0.1), f(0.012), f(10.0) / f(100)
+    n_steps = int(S1 / dt)                                               # common.cuh:322
+    assert n_steps == 500
+    g = _np_normals(o, seed, n, n_steps)
+    r1 = np.full(n, r0, np.float32)
+    r2 = r1.copy()
+    i1 = np.zeros(n, np.float32)
+    i2 = i1.copy()
+    for i in range(n_steps):                                             # common.cuh:325-332
+        sig_g = (sig_st * g[:, i]).astype(np.float32)
+        r1, i1 = _np_step(r1, i1, drift[i], sig_g, e, dt)
+        r2, i2 = _np_step(r2, i2, drift[i], (-sig_g).astype(np.float32), e, dt)
+    B = (f(1) - np.exp(-a * (S2 - S1), dtype=np.float32)) / a           # B_func
+    P0T, P0t, f0t = _np_interp(P, S2, spacing), _np_interp(P, S1, spacing), _np_interp(fw, S1, spacing)
+    term3 = (sigma * sigma / (f(4) * a)) * (f(1) - np.exp(f(-2) * a * S1, dtype=np.float32)) * B * B
+    A = (P0T / P0t) * np.exp(f(B * f0t - term3), dtype=np.float32)      # compute_A_HW
+    P1 = (A * np.exp((-B * r1).astype(np.float32))).astype(np.float32)  # compute_P_HW
+    P2 = (A * np.exp((-B * r2).astype(np.float32))).astype(np.float32)
+    d1, d2 = np.exp(-i1).astype(np.float32), np.exp(-i2).astype(np.float32)
+    c1, c2 = d1 * P1, d2 * P2
+    x1, x2 = d1 * np.maximum(P1 - K, f(0)), d2 * np.maximum(P2 - K, f(0))
+    sums = np.array([np.sum((x1 + x2).astype(np.float64)), np.sum((c1 + c2).astype(np.float64)),
+                     np.sum((x1 * x1 + x2 * x2).astype(np.float64)), np.sum((c1 * c1 + c2 * c2).astype(np.float64)),
+                     np.sum((x1 * c1 + x2 * c2).astype(np.float64))])
+    np.testing.assert_allclose(sums, o.zbc_moments(P, fw, n, seed), rtol=2e-6)
+    assert sums[0] > 0 and np.count_nonzero(x1 + x2) > n // 4           # the option is in the money on a fair share of the paths
+
+
+def test_second_restatement_of_the_curve_body_in_numpy(oracle_mod):
+    """simulate_zcb (market_data.cuh:35-67): both antithetic legs, exp(-integral) summed at every SAVE_STRIDE-th step,
+    P_sum[0] = 2 N, in NumPy float32 on 96 pairs against the C oracle's P_sum[101]."""
+    f = np.float32
+    o = oracle_mod.Oracle("head")
+    n, seed, n_steps, stride = 96, 777, 1000, 10
+    dt, _, e, sig_st = (f(x) for x in o.constants()[:4])
+    drift, _ = o.tables()
+    g = _np_normals(o, seed, n, n_steps)
+    r1 = np.full(n, f(0.012), np.float32)
+    r2 = r1.copy()
+    i1 = np.zeros(n, np.float32)
+    i2 = i1.copy()
+    want = np.zeros(101)
+    want[0] = 2.0 * n
+    for i in range(1, n_steps + 1):
+        sig_g = (sig_st * g[:, i - 1]).astype(np.float32)
+        r1, i1 = _np_step(r1, i1, drift[i - 1], sig_g, e, dt)
+        r2, i2 = _np_step(r2, i2, drift[i - 1], (-sig_g).astype(np.float32), e, dt)
+        if i % stride == 0:
+            want[i // stride] = np.sum((np.exp(-i1).astype(np.float32) + np.exp(-i2).astype(np.float32)).astype(np.float64))
+    np.testing.assert_allclose(o.zcb_curve(n, seed), want, rtol=2e-6)
