@@ -292,3 +292,38 @@ def test_second_restatement_of_the_curve_body_in_numpy(oracle_mod):
         if i % stride == 0:
             want[i // stride] = np.sum((np.exp(-i1).astype(np.float32) + np.exp(-i2).astype(np.float32)).astype(np.float64))
     np.testing.assert_allclose(o.zcb_curve(n, seed), want, rtol=2e-6)
+
+
+def test_second_restatement_of_the_vega_body_in_numpy(oracle_mod, hwmc_mod):
+    """simulate_sensitivity + compute_dP_dsigma (3_sensitivity_analysis.cu:15-19, 36-80): r and d_sigma r driven by the same
+    normal, one path per draw, in NumPy float32 on 160 paths against the C oracle's pathwise-Vega sum."""
+    f = np.float32
+    p = hwmc_mod.default_params("readme")
+    P, fw = hwmc_mod.analytic_curve(p)
+    o = oracle_mod.Oracle("readme")
+    n, seed, S1, S2, K = 160, 4242, f(5.0), f(10.0), f(np.exp(f(-0.1)))
+    dt, _, e, sig_st = (f(x) for x in o.constants()[:4])
+    drift, sdrift = o.tables()
+    a, sigma, spacing = f(1.0), f(0.1), f(10.0) / f(100)
+    n_steps = int(S1 / dt)
+    g = _np_normals(o, seed, n, n_steps)
+    r = np.full(n, f(0.012), np.float32)
+    dr = np.zeros(n, np.float32)
+    ir = np.zeros(n, np.float32)
+    idr = np.zeros(n, np.float32)
+    for i in range(1, n_steps + 1):                                      # 3_sens:47-61
+        r, ir = _np_step(r, ir, drift[i - 1], (sig_st * g[:, i - 1]).astype(np.float32), e, dt)
+        dr, idr = _np_step(dr, idr, sdrift[i - 1], ((sig_st / sigma) * g[:, i - 1]).astype(np.float32), e, dt)
+    B = (f(1) - np.exp(-a * (S2 - S1), dtype=np.float32)) / a
+    P0T, P0t, f0t = _np_interp(P, S2, spacing), _np_interp(P, S1, spacing), _np_interp(fw, S1, spacing)
+    term3 = (sigma * sigma / (f(4) * a)) * (f(1) - np.exp(f(-2) * a * S1, dtype=np.float32)) * B * B
+    A = (P0T / P0t) * np.exp(f(B * f0t - term3), dtype=np.float32)
+    Pv = (A * np.exp((-B * r).astype(np.float32))).astype(np.float32)   # 3_sens:65
+    disc = np.exp(-ir).astype(np.float32)                               # 3_sens:68
+    one_minus = f(1) - np.exp(f(-2) * a * S1, dtype=np.float32)
+    dP = (-Pv * B * (sigma / (f(2) * a) * one_minus * B + dr)).astype(np.float32)      # compute_dP_dsigma
+    term1 = np.where(Pv > K, dP * disc, f(0)).astype(np.float32)        # 3_sens:72-74
+    term2 = (idr * disc * np.maximum(Pv - K, f(0))).astype(np.float32)  # 3_sens:77-78
+    got = float(np.sum((term1 - term2).astype(np.float64)))
+    assert got == pytest.approx(o.vega_pathwise(P, fw, n, seed), rel=3e-6)
+    assert 0.1 < got / n < 0.4                                           # a Vega near 0.23 on 160 paths
