@@ -638,6 +638,7 @@ def main():
             msv.append(float(e.profile_read(1)[0]))
         mv = float(np.median(msv))
         extras["q3_vega_gpu"] = {"paths": 1 << 20, "grid_steps": a.grid_steps, "kernel_ms": mv, "value": ((1 << 20) / mv) / 1000.0,
+                                 "kernel_ms_for_valu": mv,
                                  "unit": "M paths/s", "vs_v100_509": (((1 << 20) / mv) / 1000.0) / V100_PUBLISHED_Q3_MPATHS,
                                  "reference_metric": "throughput = (N_PATHS/ms)/1000, src/3_sensitivity_analysis.cu:266 (single paths, not pairs)",
                                  "note": "pathwise Vega kernel alone on the chip, hipEvent pair around the path kernel, median of 5"}
@@ -784,6 +785,14 @@ def main():
                                "(the stream-lifetime rule of include/hw_mc.h)" % R_side},
             "device": info["name"],
         }
+        if "q3_vega_gpu" in extras and bcyc:
+            # the Vega kernel runs the SAME time loop (ou_walk: identical instruction census, tests/test_kernel_census.py), one PATH
+            # per thread where the ZBC kernel has one pair: the measured bound applies to it as it stands
+            q3 = extras["q3_vega_gpu"]
+            q3_cyc = q3.pop("kernel_ms_for_valu") * 1e-3 * mhz * 1e6 * info["compute_units"] * 4 / (((1 << 20) // 64) * (steps_exec / 4.0))
+            q3["valu"] = {"achieved_cycles_per_block_isolated_launch": q3_cyc, "bound_cycles_per_block": bcyc, "frac": bcyc / q3_cyc}
+        elif "q3_vega_gpu" in extras:
+            extras["q3_vega_gpu"].pop("kernel_ms_for_valu", None)
         line.update(extras)
         if dist_on:
             line["multi_gpu"] = {"all_reduce": "5 f64 per pricing call" if B == 1 else "5 f64 x %d steps per message" % B,

@@ -191,6 +191,17 @@ def test_other_kernels_have_no_scratch_and_full_occupancy(listing):
         assert meta["ScratchSize"] == 0 and meta["Occupancy"] >= occ, (pat, meta)
 
 
+def test_vega_kernel_runs_the_same_time_loop_as_the_zbc_kernel(listing):
+    """bench.py quotes the measured issue bound of the ZBC loop for the pathwise-Vega kernel too (q3_vega_gpu.valu): both
+    kernels call the same ou_walk, and their hot loops must hold the same instructions, opcode by opcode."""
+    def best_loop(pattern):
+        lines, _ = _kernel(listing, pattern)
+        loops = _hot_loops(lines)
+        c = min(loops, key=lambda c: (c["v_mad_u64_u32"], sum(v for k, v in c.items() if k.startswith("v_"))))
+        return {k: v for k, v in c.items() if k.startswith("v_")}
+    assert best_loop("vega_pathwise_kernelIfLi1E") == best_loop("zbc_superposed_kernelIfLi1ELi1E")
+
+
 def test_the_issue_bound_probe_times_the_production_loop():
     """bench.py's valu.bound_cycles_per_block comes from tools/mix_bound.hip, whose loop bodies (tools/mix_bound_body.inc)
     are GENERATED from the production kernel's gfx950 listing with the data dependencies removed (tools/gen_mix_bound.py).
