@@ -8,6 +8,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+export HWMC_BENCH_NO_LIVE_BOUND=1   # bench.py must not start its issue-bound probe (a child process) under the profiler
 cd /tmp
 BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --spinup-ms 200 --no-cpu-baseline --no-extras"
 echo "rocprofv3 <--kernel-trace --stats | --pmc ...> -- $BENCH" | sed "s#$ROOT/##" > "$OUT/command.txt"
