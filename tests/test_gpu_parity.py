@@ -692,6 +692,55 @@ def test_full_size_properties_of_the_multi_gpu_shares(setup, hwmc_mod):
     assert v32 == pytest.approx(v64, rel=REL_F32) and v64 == pytest.approx(0.230244, abs=1e-3)
 
 
+def test_random_models_against_the_double_oracle(hwmc_mod, oracle_mod):
+    """The reference hard-codes one model (common.cuh:16-39); the C ABI takes it as parameters.  24 random models -- mean
+    reversion, volatility, r0, both theta pieces and the break, grid lengths that are and are not multiples of four, maturity
+    counts, exercise / maturity / strike -- through all three kernels of the DOUBLE engine against the double oracle at 2e-6
+    (same normals, so this is sharp: a wrong index, table entry or hoisted constant shows as 1e-3 or worse), and the float
+    engine against the same double sums at 5e-5 (float steppers drift ~1e-5 from double away from a = 1, see the
+    weak-mean-reversion test)."""
+    rng = np.random.default_rng(20250607)
+    for case in range(24):
+        n_mat = int(rng.choice([11, 21, 51, 101]))
+        per = int(rng.choice([2, 3, 4, 5, 8, 10, 12]))                     # steps per maturity: odd ones take the generic curve kernel
+        n_steps = per * (n_mat - 1)
+        T_final = float(rng.choice([5.0, 10.0, 20.0]))
+        fields = dict(a=float(rng.uniform(0.3, 2.0)), sigma=float(rng.uniform(0.02, 0.2)), r0=float(rng.uniform(0.0, 0.05)),
+                      T_final=T_final, th_break=float(rng.uniform(0.2, 0.8)) * T_final, th_a1=float(rng.uniform(0.0, 0.03)),
+                      th_b1=float(rng.uniform(-0.001, 0.003)), th_a2=float(rng.uniform(0.0, 0.03)), th_b2=float(rng.uniform(-0.001, 0.003)))
+        spacing = T_final / (n_mat - 1)
+        i1 = int(rng.integers(1, n_mat - 1))
+        S1, S2 = i1 * spacing, float(rng.uniform(i1 * spacing + 0.3 * spacing, T_final))
+        engines = {}
+        try:
+            for prec in ("f64", "f32"):
+                p = hwmc_mod.default_params("head", n_steps=n_steps, n_mat=n_mat, precision=prec)
+                for k, v in fields.items():
+                    setattr(p, k, v)
+                engines[prec] = hwmc_mod.HullWhiteEngine(p, device=0)
+            P, f = hwmc_mod.analytic_curve(engines["f64"].params)
+            o = oracle_mod.Oracle("head", n_steps=n_steps, n_mat=n_mat, precision="f64")
+            for k, v in fields.items():
+                setattr(o.m, k, v)
+            fwd = float(np.interp(S2, np.arange(n_mat) * spacing, P) / np.interp(S1, np.arange(n_mat) * spacing, P))
+            K = fwd * float(rng.uniform(0.97, 1.03))                        # around the money
+            n, seed = int(rng.integers(500, 6000)), int(rng.integers(1, 1 << 40))
+            want = o.zbc_moments(P, f, n, seed, S1=S1, S2=S2, K=K)
+            wantc = o.zcb_curve(n, seed)
+            wantv = o.vega_pathwise(P, f, n, seed, S1=S1, S2=S2, K=K)
+            for prec, tol in (("f64", REL_F64), ("f32", 5e-5)):
+                e = engines[prec]
+                e.load_market_data(P, f)
+                tag = (case, prec, fields, n_steps, n_mat, S1, S2, K)
+                np.testing.assert_allclose(e.simulate_ZBC_control_variate(n, seed, S1=S1, S2=S2, K=K), want, rtol=tol, atol=tol * abs(want[1]) * 1e-3, err_msg=str(tag))
+                np.testing.assert_allclose(e.simulate_zcb(n, seed), wantc, rtol=tol, err_msg=str(tag))
+                got = e.simulate_sensitivity(n, seed, S1=S1, S2=S2, K=K)
+                assert abs(got - wantv) <= 20 * tol * max(abs(wantv), 1e-3 * n), (tag, got, wantv)   # a sum of terms of both signs
+        finally:
+            for e in engines.values():
+                e.close()
+
+
 def test_configs_3_and_4_whole_on_one_gpu(setup, hwmc_mod):
     """BASELINE configs[3] (Q2b, 2^24 pairs, 8 GPUs, all-reduce of the moments) and configs[4] (2^26 pairs x 4000-step grid,
     f32 vs f64, 8 GPUs) at their FULL path counts -- on the one GPU this suite has: the sample set depends only on
