@@ -695,7 +695,7 @@ def test_full_size_properties_of_the_multi_gpu_shares(setup, hwmc_mod):
 def test_random_models_against_the_double_oracle(hwmc_mod, oracle_mod):
     """The reference hard-codes one model (common.cuh:16-39); the C ABI takes it as parameters.  24 random models -- mean
     reversion, volatility, r0, both theta pieces and the break, grid lengths that are and are not multiples of four, maturity
-    counts, exercise / maturity / strike -- through all three kernels of the DOUBLE engine against the double oracle at 2e-6
+    counts, exercise / maturity / strike -- through all three kernels, the FD scenarios, the batched runs and (float) the reference stepper, DOUBLE engine against the double oracle at 2e-6
     (same normals, so this is sharp: a wrong index, table entry or hoisted constant shows as 1e-3 or worse), and the float
     engine against the same double sums at 5e-5 (float steppers drift ~1e-5 from double away from a = 1, see the
     weak-mean-reversion test)."""
@@ -736,6 +736,17 @@ def test_random_models_against_the_double_oracle(hwmc_mod, oracle_mod):
                 np.testing.assert_allclose(e.simulate_zcb(n, seed), wantc, rtol=tol, err_msg=str(tag))
                 got = e.simulate_sensitivity(n, seed, S1=S1, S2=S2, K=K)
                 assert abs(got - wantv) <= 20 * tol * max(abs(wantv), 1e-3 * n), (tag, got, wantv)   # a sum of terms of both signs
+                # the finite-difference scenarios (sigma -+ eps with the shifted drift table, 3_sens:374-446) from ONE pass
+                s0, eps = fields["sigma"], 1e-3
+                sc = e.simulate_ZBC_scenarios(n, seed, [s0 - eps, s0 + eps], [hwmc_mod.HW_DRIFT_SHIFTED] * 2, S1=S1, S2=S2, K=K)
+                for k, sg in enumerate((s0 - eps, s0 + eps)):
+                    np.testing.assert_allclose(sc[k], o.zbc_moments(P, f, n, seed, S1=S1, S2=S2, K=K, sigma=sg, drift=o.shifted_drift(sg, s0)),
+                                               rtol=tol, atol=tol * abs(want[1]) * 1e-3, err_msg=str(tag))
+                np.testing.assert_allclose(e.simulate_ZBC_runs(n, seed, n_runs=3, seed_stride=977, S1=S1, S2=S2, K=K)[2],
+                                           o.zbc_moments(P, f, n, seed + 2 * 977, S1=S1, S2=S2, K=K), rtol=tol, atol=tol * abs(want[1]) * 1e-3, err_msg=str(tag))
+            # the reference stepper (float only): evolve_hull_white_step verbatim with the drift table on the device
+            ref = engines["f32"].simulate_ZBC_control_variate(n, seed, S1=S1, S2=S2, K=K, stepper=hwmc_mod.HW_STEPPER_REFERENCE)
+            np.testing.assert_allclose(ref, want, rtol=5e-5, atol=5e-8 * abs(want[1]), err_msg=str((case, "reference stepper", fields)))
         finally:
             for e in engines.values():
                 e.close()
