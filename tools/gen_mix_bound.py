@@ -221,6 +221,8 @@ def generate(search=0):
         variants[name + "_NOPRIO"] = ([x for x in free if not x.startswith(("s_setprio", "s_nop"))], blocks)
         real = [i for i in loop if not i.startswith(("s_cbranch", "s_cmp", "s_branch"))]
         variants["REAL" + name[-1]] = (real, blocks)
+        if name == "PROD1":      # the same loop on priority levels 2/3 instead of 0/1 (tools/pace_lab.hip: rotating priorities)
+            variants["REAL1_HI"] = ([re.sub(r"^s_setprio ([01])$", lambda m: "s_setprio %d" % (int(m.group(1)) + 2), x) for x in real], blocks)
     valu = [x for x in variants["PROD1_NOPRIO"][0] if x.startswith("v_")]
     order = {"half": 0, "quarter": 1, "full": 2}
     grouped = sorted(valu, key=lambda x: (order[klass(x.split()[0])], x.split()[0].startswith("v_cvt")))
@@ -248,9 +250,9 @@ def generate(search=0):
              % (c2["full"], c2["half"], c2["quarter"]))
     for name, (lines, blocks) in variants.items():
         emit(name, lines, blocks, fh, census_of(lines))
-    full = {"PROD1", "PROD1_NOPRIO", "PROD2", "PROD2_NOPRIO", "GROUPED", "GROUPED_PRIO", "REAL1", "REAL2"}
+    full = {"PROD1", "PROD1_NOPRIO", "PROD2", "PROD2_NOPRIO", "GROUPED", "GROUPED_PRIO", "REAL1", "REAL2", "REAL1_HI"}
     fh.write("#define MIX_VARIANTS(X) \\\n" + " \\\n".join(
-        "    X(%s, %d, %d)" % (name, 0 if name.startswith("REAL") else 1, 1 if name in full else 0) for name in variants) + "\n")
+        "    X(%s, %d, %d)" % (name, 0 if name.startswith("REAL") else 1, 1 if name in full else 0) for name in variants if name != "REAL1_HI") + "\n")
     return fh.getvalue()
 
 

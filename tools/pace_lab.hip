@@ -69,6 +69,32 @@
     "2:\n\t"
 // only the clock read and the wait for it, no comparison: what does reading the clock cost?
 #define LAB_PACE_READONLY "s_waitcnt lgkmcnt(0)\n\t"
+// ROTATING PRIORITIES: no wave sleeps; instead every wave runs the loop on priority levels 2/3 during the phases of its
+// OWN progress in which ((trips >> shift) ^ group) is odd, and on the production levels 0/1 otherwise.  group = one bit per
+// wave (mode picks which).  A wave that is ahead reaches its low phase sooner and yields to the others.
+#define LAB_KERNEL_ROT(NAME)                                                                                            \
+    __global__ void __launch_bounds__(512) NAME(unsigned long long* out, unsigned dlo, unsigned dhi, int shift, int mode) \
+    {                                                                                                                   \
+        const int wave = threadIdx.x >> 6;                                                                              \
+        int group = mode == 0 ? (wave >> 2) : mode == 1 ? (int)blockIdx.x : mode == 2 ? ((wave >> 2) ^ (int)blockIdx.x) \
+                                                                         : (int)(blockIdx.x / (gridDim.x / 2));         \
+        group = __builtin_amdgcn_readfirstlane(group & 1);                                                              \
+        unsigned clo, chi, rlo, rhi, elo, ehi;                                                                          \
+        asm volatile(LAB_PROLOGUE                                                                                       \
+                     "s_lshr_b32 s39, s38, %[shift]\n\ts_xor_b32 s39, s39, %[group]\n\ts_and_b32 s39, s39, 1\n\t"        \
+                     "s_cmp_eq_u32 s39, 0\n\ts_cbranch_scc1 5f\n\t"                                                     \
+                     MIX_BODY_REAL1_HI "s_branch 6f\n\t5:\n\t" MIX_BODY_REAL1 "6:\n\t" LAB_EPILOGUE                    \
+                     : [clo] "=s"(clo), [chi] "=s"(chi), [rlo] "=s"(rlo), [rhi] "=s"(rhi), [elo] "=s"(elo), [ehi] "=s"(ehi) \
+                     : [dlo] "s"(dlo), [dhi] "s"(dhi), [shift] "s"(shift), [group] "s"(group)                          \
+                     : LAB_CLOBBERS, MIX_CLOBBERS_REAL1);                                                               \
+        if ((threadIdx.x & 63) == 0) {                                                                                  \
+            const size_t w = (size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);                               \
+            out[3 * w] = ((unsigned long long)chi << 32) | clo;                                                         \
+            out[3 * w + 1] = ((unsigned long long)rhi << 32) | rlo;                                                     \
+            out[3 * w + 2] = ((unsigned long long)ehi << 32) | elo;                                                     \
+        }                                                                                                               \
+    }
+LAB_KERNEL_ROT(lab_rotate)
 LAB_KERNEL(lab_plain, "", "")
 LAB_KERNEL(lab_paced, LAB_TOP_PACED, LAB_PACE)
 LAB_KERNEL(lab_paced4, LAB_TOP_PACED4, LAB_PACE4)
@@ -121,5 +147,30 @@ int main(int argc, char** argv)
             else snprintf(name, sizeof name, "paced%s %+.1f%% slack %.0f blk", mode >= 6 ? "/4" : "", 100 * margin[mode], slack_blocks[mode]);
             printf("%-28s %6d %10.2f %9.0f %9.0f %9.0f %9.0f %9.0f\n", name, occ, best, bt.front(), bt[waves / 10], bt[waves / 2], bt[waves * 9 / 10], bt.back());
         }
+    printf("\nrotating priorities (levels 2/3 while ((trips >> shift) ^ group) is odd, else 0/1)\n");
+    for (int occ : {4, 6, 8})
+        for (int mode = 0; mode < 4; mode++)
+            for (int shift : {0, 2, 4, 6}) {
+                const int grid = cus * occ / 2;
+                const size_t waves = (size_t)grid * 8;
+                double best = 1e30; std::vector<double> bt;
+                for (int rep = 0; rep < 3; rep++) {
+                    const unsigned long long dl = deadline();
+                    hipLaunchKernelGGL(lab_rotate, dim3(grid), dim3(512), 0, 0, d_out, (unsigned)dl, (unsigned)(dl >> 32), shift, mode);
+                    CHECK(hipGetLastError());
+                    CHECK(hipMemcpy(h.data(), d_out, waves * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                    double cyc = 0, real = 0, trips = 0; unsigned long long first = ~0ull, last = 0; std::vector<double> t(waves);
+                    for (size_t w = 0; w < waves; w++) {
+                        t[w] = (double)(h[3 * w] >> 32); trips += t[w]; cyc += (double)(h[3 * w] & 0xffffffffull); real += (double)(h[3 * w + 2] - h[3 * w + 1]);
+                        first = std::min(first, h[3 * w + 1]); last = std::max(last, h[3 * w + 2]);
+                    }
+                    const double mhz = cyc / real * 100.0, per = (double)cus * 4.0 * (double)(last - first) * mhz / 100.0 / trips;
+                    if (per < best) { best = per; std::sort(t.begin(), t.end()); bt = t; }
+                }
+                const char* gname[] = {"wave>>2", "block", "wave>>2 ^ block", "block half"};
+                char name[64];
+                snprintf(name, sizeof name, "rotate %s, %d trips", gname[mode], 1 << shift);
+                printf("%-28s %6d %10.2f %9.0f %9.0f %9.0f %9.0f %9.0f\n", name, occ, best, bt.front(), bt[waves / 10], bt[waves / 2], bt[waves * 9 / 10], bt.back());
+            }
     return 0;
 }
