@@ -58,7 +58,7 @@ def listing():
     flags = [f for f in hwmc.HIPCC_FLAGS if f not in ("-fPIC", "-shared")]
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "eng.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "--cuda-device-only", "-S", "-o", out,
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), *flags, "--cuda-device-only", "-S", "-o", out,
                                os.path.join(PKG, "csrc", "hw_engine.hip")], stderr=subprocess.DEVNULL)
         return open(out).read()
 
@@ -314,13 +314,15 @@ def main():
         print("wrote", out)
         return
     text = generate()
+    out_path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else OUT     # --out FILE: write somewhere else (build() does, for a stale body)
     if "--check" in sys.argv:
         ok = os.path.exists(OUT) and open(OUT).read() == text
         print("mix_bound_body.inc is %s" % ("up to date" if ok else "STALE: run python tools/gen_mix_bound.py"))
         sys.exit(0 if ok else 1)
-    with open(OUT, "w") as fh:
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    with open(out_path, "w") as fh:
         fh.write(text)
-    print("wrote", OUT)
+    print("wrote", out_path)
 
 
 if __name__ == "__main__":
