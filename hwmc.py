@@ -18,4 +18,9 @@ _pkg = sys.modules[_NAME]
 globals().update({k: getattr(_pkg, k) for k in _pkg.__all__})
 PACKAGE_DIR = _PKG_DIR
 LIB_PATH = _pkg._lib.LIB_PATH
-SIGNATURES = _pkg._lib.SIGNATURES
+SIGNATURES = _pkg._lib.SIGNATURES            # include/hw_mc.h
+DIAG_SIGNATURES = _pkg._lib.DIAG_SIGNATURES  # include/hw_mc_diag.h
+
+
+def _lib_abi_version():
+    return _pkg._lib.ABI_VERSION

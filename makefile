@@ -15,7 +15,7 @@ all: q1 q2 q3
 
 lib: $(LIB)
 
-$(LIB): $(PKG)/csrc/hw_engine.hip $(PKG)/csrc/hw_kernels.hpp $(PKG)/csrc/hw_model.hpp $(PKG)/csrc/hw_stream_guard.hpp $(PKG)/csrc/hw_fleet.hpp include/hw_mc.h
+$(LIB): $(PKG)/csrc/hw_engine.hip $(PKG)/csrc/hw_kernels.hpp $(PKG)/csrc/hw_model.hpp $(PKG)/csrc/hw_stream_guard.hpp $(PKG)/csrc/hw_fleet.hpp include/hw_mc.h include/hw_mc_diag.h
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -Wshadow -fno-slp-vectorize -fPIC -shared $(PKG)/csrc/hw_engine.hip -o $@
 
 q1: $(SRC)/1_bond_pricing.cpp $(SRC)/hw_app.hpp $(LIB)

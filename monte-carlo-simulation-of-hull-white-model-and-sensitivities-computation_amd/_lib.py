@@ -16,6 +16,7 @@ HW_TABLES_F64, HW_TABLES_REF_F32 = 0, 1
 HW_STEPPER_SUPERPOSED, HW_STEPPER_REFERENCE = 0, 1
 HW_DRIFT_BASE, HW_DRIFT_SHIFTED = 0, 1
 HW_COMM_RCCL, HW_COMM_HOST_SUM = 0, 1
+ABI_VERSION = 5                 # HW_ABI_VERSION of include/hw_mc.h
 
 
 class HwParams(C.Structure):
@@ -48,7 +49,7 @@ _DP = C.POINTER(C.c_double)
 _FP = C.POINTER(C.c_float)
 _CTX = C.c_void_p
 
-# name -> (restype, argtypes); every symbol include/hw_mc.h declares
+# name -> (restype, argtypes); every symbol include/hw_mc.h declares (the stable boundary)
 SIGNATURES = {
     "hw_abi_version": (C.c_int, []),
     "hw_last_error": (C.c_char_p, []),
@@ -58,7 +59,6 @@ SIGNATURES = {
     "hw_get_device_info": (C.c_int, [_CTX, C.POINTER(HwDeviceInfo)]),
     "hw_get_params": (C.c_int, [_CTX, C.POINTER(HwParams)]),
     "hw_set_market": (C.c_int, [_CTX, _FP, _FP, C.c_int32]),
-    "hw_set_launch": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "hw_zbc_moments": (C.c_int, [_CTX, C.POINTER(HwZbcRequest), _DP, _FP]),
     "hw_zbc_moments_async": (C.c_int, [_CTX, C.POINTER(HwZbcRequest), C.c_void_p, C.c_void_p]),
     "hw_zbc_moments_runs": (C.c_int, [_CTX, C.POINTER(HwZbcRequest), C.c_int32, C.c_uint64, _DP, _FP]),
@@ -74,16 +74,6 @@ SIGNATURES = {
     "hw_vega_pathwise_async": (C.c_int, [_CTX, C.c_int64, C.c_uint64, C.c_uint64, C.c_double,
                                          C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p]),
     "hw_sample_paths": (C.c_int, [_CTX, C.c_int32, C.c_uint64, C.c_uint64, _FP]),
-    "hw_debug_normals": (C.c_int, [_CTX, C.c_uint64, C.c_uint64, C.c_int32, _FP]),
-    "hw_debug_raw": (C.c_int, [_CTX, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_uint32)]),
-    "hw_debug_exp2": (C.c_int, [_CTX, _DP, C.c_int32, _DP]),
-    "hw_profile_enable": (C.c_int, [_CTX, C.c_int32]),
-    "hw_profile_read": (C.c_int, [_CTX, _FP, C.c_int32, C.POINTER(C.c_int32)]),
-    "hw_profile_clock": (C.c_int, [_CTX, _DP]),
-    "hw_profile_spans": (C.c_int, [_CTX, _CTX, _FP, _FP, C.c_int32, C.POINTER(C.c_int32)]),
-    "hw_get_launch_geometry": (C.c_int, [_CTX, C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
-                                         C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
-    "hw_get_kernel_info": (C.c_int, [_CTX, C.c_char_p, C.POINTER(HwKernelInfo)]),
     "hw_comm_create": (C.c_int, [C.c_int32, C.POINTER(_CTX), C.POINTER(C.c_void_p)]),
     "hw_comm_create_ex": (C.c_int, [C.c_int32, C.POINTER(_CTX), C.c_int32, C.POINTER(C.c_void_p)]),
     "hw_comm_destroy": (None, [C.c_void_p]),
@@ -102,6 +92,21 @@ SIGNATURES = {
     "hw_recover_theta": (C.c_int, [C.POINTER(HwParams), _FP, _FP, _FP, _FP]),
     "hw_cv_price": (C.c_int, [_DP, C.c_int64, C.c_double, _DP]),
     "hw_analytic_curve": (C.c_int, [C.POINTER(HwParams), _FP, _FP]),
+}
+
+# ... and every symbol include/hw_mc_diag.h declares (launch knobs, kernel resources, device probes, profiling hooks)
+DIAG_SIGNATURES = {
+    "hw_set_launch": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "hw_debug_normals": (C.c_int, [_CTX, C.c_uint64, C.c_uint64, C.c_int32, _FP]),
+    "hw_debug_raw": (C.c_int, [_CTX, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_uint32)]),
+    "hw_debug_exp2": (C.c_int, [_CTX, _DP, C.c_int32, _DP]),
+    "hw_profile_enable": (C.c_int, [_CTX, C.c_int32]),
+    "hw_profile_read": (C.c_int, [_CTX, _FP, C.c_int32, C.POINTER(C.c_int32)]),
+    "hw_profile_clock": (C.c_int, [_CTX, _DP]),
+    "hw_profile_spans": (C.c_int, [_CTX, _CTX, _FP, _FP, C.c_int32, C.POINTER(C.c_int32)]),
+    "hw_get_launch_geometry": (C.c_int, [_CTX, C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "hw_get_kernel_info": (C.c_int, [_CTX, C.c_char_p, C.POINTER(HwKernelInfo)]),
 }
 
 _lib = None
@@ -123,11 +128,11 @@ def load():
             "%s is missing: the HIP engine has not been built (run __graft_entry__.build() or "
             "`make -C <package>/csrc`).  There is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(DIAG_SIGNATURES.items()):
         fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
-    if lib.hw_abi_version() != 4:
+    if lib.hw_abi_version() != ABI_VERSION:
         raise ImportError("libhw_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -13,7 +13,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     deps = [os.path.join(CSRC, s) for s in SOURCES]
-    deps.append(os.path.join(_HERE, "..", "include", "hw_mc.h"))
+    deps += [os.path.join(_HERE, "..", "include", h) for h in ("hw_mc.h", "hw_mc_diag.h")]
     return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
 
 

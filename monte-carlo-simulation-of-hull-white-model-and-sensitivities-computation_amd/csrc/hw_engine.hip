@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../include/hw_mc.h"
+#include "../../include/hw_mc_diag.h"
 #include "hw_kernels.hpp"
 #include "hw_model.hpp"
 #include "hw_stream_guard.hpp"

@@ -4,6 +4,7 @@
 // prompts, writes data/q3_results.json, optional data/vega_bootstrap.csv + data/vega_statistics.txt,
 // appends data/summary.txt.
 #include "hw_app.hpp"
+#include "../include/hw_mc_diag.h"   // hw_get_kernel_info / hw_set_launch: the block-size sweep of run_sensitivity_mc (3_sens:183-239)
 
 static const double kS1 = 5.0, kS2 = 10.0, kEps = 0.001;      // 3_sens:175-177, :404-405
 

@@ -9,24 +9,33 @@ import numpy as np
 import pytest
 
 
-def _declared_symbols():
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    text = open(os.path.join(root, "include", "hw_mc.h")).read()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(hw_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_builds_and_exports_every_declared_symbol(hwmc_mod):
+    """Both headers against the library and the Python binding: include/hw_mc.h is the stable boundary (what
+    INTEGRATION.md binds), include/hw_mc_diag.h the knobs / probes / profiling hooks; together they are EXACTLY what
+    libhw_hip.so exports under hw_*, and no diagnostic name sits in the stable header."""
     assert os.path.exists(hwmc_mod.LIB_PATH)
-    declared = _declared_symbols()
-    assert len(declared) >= 24
-    assert sorted(hwmc_mod.SIGNATURES) == declared        # python binding covers the whole header
+    stable, diag = _declared_symbols("hw_mc.h"), _declared_symbols("hw_mc_diag.h")
+    assert len(stable) >= 24 and not set(stable) & set(diag)
+    assert sorted(hwmc_mod.SIGNATURES) == stable          # python binding covers the whole stable header ...
+    assert sorted(hwmc_mod.DIAG_SIGNATURES) == diag       # ... and the whole diagnostic one
+    assert not [n for n in stable if n.startswith(("hw_debug_", "hw_profile_")) or n in ("hw_set_launch", "hw_get_kernel_info", "hw_get_launch_geometry")]
     lib = C.CDLL(hwmc_mod.LIB_PATH)
-    for name in declared:
+    for name in stable + diag:
         assert hasattr(lib, name), name
     out = subprocess.run(["nm", "-D", "--defined-only", hwmc_mod.LIB_PATH], capture_output=True, text=True).stdout
-    for name in declared:
-        assert re.search(r"\bT %s\b" % name, out), name
+    exported = sorted(set(re.findall(r"\bT (hw_[a-z0-9_]+)\b", out)))
+    assert exported == sorted(stable + diag)              # nothing exported that no header declares
+    version = int(re.search(r"#define HW_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "hw_mc.h")).read()).group(1))
+    assert lib.hw_abi_version() == version == hwmc_mod._lib_abi_version()
 
 
 def test_library_contains_gfx950_code_object(hwmc_mod):
