@@ -33,13 +33,20 @@ single-stream run, and the line carries the strictly serial rate ("serial") and 
 Side measurements in the same line (untimed, N = 1; --no-extras drops them): `long_region` (10 K steps between two
 synchronisations: what starting and draining the pipeline once per K steps costs), `library_pipeline` (the same K calls
 through the C ABI's own hw_pipe_zbc_moments: one function call, no torch), `other_stepper`, `runs20_single_launch`,
-`q1_curve_gpu`, `q3_vega_gpu` (the reference's other two published rates, README.md:161-163), `strong_scaling_reference`;
+`q1_curve_gpu`, `q3_vega_gpu` (the reference's other two published rates, README.md:161-163), `q3_fd_vega_gpu` (the
+three-scenario finite-difference launch, 3_sens:400-446), `size_table` (2^20..2^26 pairs, kernel alone), `sync_call` (host-to-host
+time of a synchronous hw_zbc_moments call), `stress` (BASELINE configs[4] on one GPU: 2^26 pairs x 4000-step grid, float and double
+engine, ZBC stepper and curve kernel, each with its HBM and VALU fraction), `strong_scaling_reference`;
 `cpu_baseline` = the oracle on the host cores (the only use of oracle/ here).
 
-VALU bound.  `valu.bound_cycles_per_block` is MEASURED, not modelled: tools/mix_bound.hip times the production loop's own
-instruction stream with its data dependencies removed (tools/gen_mix_bound.py) in shader-clock cycles; the production
-loop cannot issue faster, so valu.frac = bound / achieved <= 1.  bench.py runs the probe live (a child process, before this
-process touches the GPU) when tools/bin/mix_bound exists, else reads the newest profiles/rNN_mix_bound.json.
+VALU bound.  `valu.bound_cycles_per_block` is MEASURED, not modelled: tools/mix_bound.hip times each production loop's own
+instruction stream with its data dependencies removed (tools/gen_mix_bound.py) in shader-clock cycles: the rate at which a
+SIMD issues that instruction mix in the production ORDER when nothing waits for a result.  It is the fastest of the orderings
+and occupancies tried, not a proven floor (the provable one, `exclusive_classes_floor`, is lower); valu.frac = bound / achieved
+is the share of a launch's SIMD time that the loop's issue rate accounts for -- the rest is prologue, epilogue, drain and
+dependency stalls.  Loops with a twin: the float ZBC/Vega loop, the double ZBC loop, the curve loop (P = 1 and P = 4 pairs per
+thread, float and double).  bench.py runs the probe live (a child process, before this process touches the GPU) when
+tools/bin/mix_bound exists, else reads the newest profiles/rNN_mix_bound.json.
 """
 import argparse
 import glob
@@ -202,6 +209,17 @@ def mix_bound(live=True):
         return d
     except (OSError, ValueError):
         return None
+
+
+def loop_bound(bound, name):
+    """cycles per Philox block per SIMD of the dependency-free twin of loop `name` ("zbc_f32", "zbc_f64", "curve_f32_p1",
+    "curve_f32_p4", "curve_f64_p4"; tools/mix_bound.hip `loops`), or None when the probe result does not carry it."""
+    if not bound:
+        return None
+    if name == "zbc_f32":
+        return bound.get("bound_cycles_per_block")
+    d = (bound.get("loops") or {}).get(name)
+    return d.get("bound_cycles_per_block") if d else None
 
 
 def union_ms(spans):
@@ -606,6 +624,34 @@ def main():
             m20 = float(np.median(ms20))
             extras["runs20_single_launch"] = {"n_runs": 20, "pairs_per_run": shard_n, "ms": m20, "value": (20 * 2 * shard_n / m20) / 1000.0,
                                               "unit": "M paths/s", "note": "path kernel + column pass of hw_zbc_moments_runs, hipEvent pair, median of 5"}
+        def isolated_ms(eng, fn, reps, pair=True):
+            """hipEvent pair tight around the path kernel of `reps` launches; pair: each timed launch directly follows an
+            untimed one (a launch that follows the idle time of reading events back runs slow)."""
+            out_ms = []
+            for _ in range(reps):
+                if pair:
+                    fn()
+                eng.profile_enable(1)
+                fn()
+                out_ms.append(float(eng.profile_read(1)[0]))
+            return out_ms
+
+        def clock_of(eng):
+            """in-kernel clock of the engine's last profiled launch; kernels without the probe: the headline kernel's clock"""
+            try:
+                return eng.profile_clock_mhz()
+            except hwmc.HwError:
+                return clock_mhz or e.device_info()["clock_mhz"]
+
+        def valu_of(ms, n_units, steps, mhz_, loop):
+            """bound / achieved for one launch alone on the chip: achieved = launch time x clock x SIMDs / (waves x Philox
+            blocks per path); bound = the measured dependency-free rate of that loop's own instruction stream."""
+            info_ = e.device_info()
+            cyc = ms * 1e-3 * mhz_ * 1e6 * info_["compute_units"] * 4 / (((n_units + 63) // 64) * (steps / 4.0))
+            b = loop_bound(bound, loop)
+            return {"loop": loop, "achieved_cycles_per_block_isolated_launch": cyc, "bound_cycles_per_block": b,
+                    "frac": (b / cyc) if b else None, "clock_mhz_in_kernel": mhz_}
+
         # the Q1 curve kernel at BASELINE configs[0]'s size (2^20 pairs x 1000 steps x 100 maturities), beside cpu_baseline.q1_curve
         pc = hwmc.default_params(a.profile, n_steps=1000, precision=a.precision)
         with hwmc.HullWhiteEngine(pc, device=local_rank) as ec:
@@ -623,7 +669,10 @@ def main():
                 print("bench: q1 curve launches ms", ["%.4f" % x for x in msq], file=sys.stderr, flush=True)
             extras["q1_curve_gpu"] = {"pairs": 1 << 20, "grid_steps": 1000, "maturities": 100, "kernel_ms": mq,
                                       "value": (2 * (1 << 20) / mq) / 1000.0, "unit": "M paths/s",
-                                      "vs_v100_391": ((2 * (1 << 20) / mq) / 1000.0) / V100_PUBLISHED_Q1_MPATHS}
+                                      "vs_v100_391": ((2 * (1 << 20) / mq) / 1000.0) / V100_PUBLISHED_Q1_MPATHS,
+                                      # the curve loop's OWN measured issue bound (Philox + Box-Muller + two half-block steps + the
+                                      # maturity events of a 16-maturity period, dependency-free: tools/gen_mix_bound.py CURVE*)
+                                      "valu": valu_of(mq, 1 << 20, 1000, clock_of(ec), "curve_%s_p1" % a.precision)}
         # the Q3 pathwise-Vega kernel at BASELINE configs[2]'s size (2^20 single paths, 500 executed steps), metric exactly
         # as src/3_sensitivity_analysis.cu:266: (N_PATHS / ms) / 1000 with the event pair around the kernel
         respin()
@@ -642,6 +691,100 @@ def main():
                                  "unit": "M paths/s", "vs_v100_509": (((1 << 20) / mv) / 1000.0) / V100_PUBLISHED_Q3_MPATHS,
                                  "reference_metric": "throughput = (N_PATHS/ms)/1000, src/3_sensitivity_analysis.cu:266 (single paths, not pairs)",
                                  "note": "pathwise Vega kernel alone on the chip, hipEvent pair around the path kernel, median of 5"}
+        if a.stepper == "superposed":
+            steps_s1 = int(round(5.0 * a.grid_steps / 10.0))
+            # (a) the finite-difference half of BASELINE configs[2]: sigma, sigma -+ eps priced from ONE pass over the same draws
+            #     (hw_zbc_scenarios) = the three launches + two state restores of run_finite_difference, 3_sens:400-446
+            respin()
+            sg0, eps = p.sigma, 1e-3
+            fd_fn = lambda sd=7: e.simulate_ZBC_scenarios(1 << 20, sd, [sg0, sg0 - eps, sg0 + eps],
+                                                         [hwmc.HW_DRIFT_BASE, hwmc.HW_DRIFT_SHIFTED, hwmc.HW_DRIFT_SHIFTED])
+            tw = time.perf_counter()
+            while (time.perf_counter() - tw) * 1e3 < 80.0:
+                fd_fn()
+            ms_fd = float(np.median(isolated_ms(e, fd_fn, 5)))
+            mhz_fd = clock_of(e)
+            sc = fd_fn(1234)
+            pr = [hwmc.cv_price(x, 2 << 20, float(P[-1]))["price"] for x in sc]
+            extras["q3_fd_vega_gpu"] = {
+                "pairs": 1 << 20, "scenarios": 3, "epsilon": eps, "kernel_ms": ms_fd,
+                "value": (2 * (1 << 20) / ms_fd) / 1000.0, "unit": "M paths/s (per scenario: all three come from one pass)",
+                "scenario_paths_per_sec_M": (3 * 2 * (1 << 20) / ms_fd) / 1000.0,
+                "vega_fd": (pr[2] - pr[1]) / (2.0 * eps), "price": pr[0],
+                "over_single_scenario_launch": ms_fd / float(np.mean(kernel_ms_isolated)) if shard_n == 1 << 20 else None,
+                "valu": valu_of(ms_fd, 1 << 20, steps_s1, mhz_fd, "zbc_" + a.precision),
+                "reference": "run_finite_difference, src/3_sensitivity_analysis.cu:400-446 (3 launches of simulate_ZBC_control_variate + 2 state restores)",
+                "note": "three-scenario path kernel alone on the chip, hipEvent pair, median of 5; valu.frac against the ONE-scenario loop's "
+                        "bound: the loop is the same, the two extra payoff epilogues are what the difference pays for"}
+            # (b) kernel alone on the chip against batch size (north_star: 'paths/sec on 2^20-2^26 paths x 1000 steps')
+            table = []
+            for lg in (20, 22, 24, 26):
+                n_ = 1 << lg
+                fn_ = lambda n_=n_: e.simulate_ZBC_control_variate(n_, 11)
+                fn_()
+                ms_ = float(np.median(isolated_ms(e, fn_, 5 if lg < 26 else 3, pair=lg < 24)))
+                row = {"pairs_log2": lg, "kernel_ms": ms_, "value": (2 * n_ / ms_) / 1000.0,
+                       "valu_frac": valu_of(ms_, n_, steps_s1, clock_of(e), "zbc_" + a.precision)["frac"]}
+                table.append(row)
+            extras["size_table"] = {"grid_steps": a.grid_steps, "steps_executed": steps_s1, "unit": "M paths/s", "rows": table,
+                                    "note": "one launch at a time, hipEvent pair around the path kernel, median of 5 (3 at 2^26)"}
+            # (c) host-to-host time of a synchronous hw_zbc_moments call (kernel_ms = NULL: no event pair, polled completion),
+            #     calls strictly one after another from this thread through ctypes with a prebuilt request
+            import ctypes as C_
+            req = e._request(1 << 20, 1234, 0, 5.0, 10.0, None, 0.0, hwmc.HW_DRIFT_BASE, hwmc.HW_STEPPER_SUPERPOSED)
+            out5 = (C_.c_double * 5)()
+            call = e.lib.hw_zbc_moments
+            ctx_, rq_ = e._ctx, C_.byref(req)
+            respin()
+            for _ in range(10):
+                call(ctx_, rq_, out5, None)
+            tcall = []
+            for k_ in range(20):
+                req.seed = 1234 + 12345 * k_
+                tq = time.perf_counter()
+                rc_ = call(ctx_, rq_, out5, None)
+                tcall.append((time.perf_counter() - tq) * 1e3)
+                assert rc_ == 0
+            sc_ms = float(np.median(tcall))
+            extras["sync_call"] = {"api": "hw_zbc_moments(ctx, req, out, NULL)", "pairs": 1 << 20, "calls": 20, "ms_per_call": sc_ms,
+                                   "ms_min": float(np.min(tcall)), "value": (2 * (1 << 20) / sc_ms) / 1000.0,
+                                   "vs_baseline": (2 * (1 << 20) / sc_ms) / 1000.0 / V100_PUBLISHED_MPATHS, "unit": "M paths/s",
+                                   "note": "host wall clock around each call (perf_counter, ctypes with a prebuilt request: ~1-2 us of binding "
+                                           "overhead included), 20 calls one after another, median; the result is on the host when the call returns"}
+            # (d) BASELINE configs[4] on ONE GPU: 2^26 pairs x 4000-step grid, float and double engine, ZBC stepper and curve kernel
+            if not os.environ.get("HWMC_BENCH_NO_STRESS"):
+                stress = {"config": "BASELINE configs[4] on one GPU: 2^26 pairs x 4000-step grid (2000 executed steps to S1 = 5 for the ZBC "
+                                    "stepper, 4000 for the curve), float32 vs float64 stepper",
+                          "pairs": 1 << 26, "grid_steps": 4000, "launches_timed": 3}
+                nS = 1 << 26
+                for prec in ("f32", "f64"):
+                    ps = hwmc.default_params(a.profile, n_steps=4000, precision=prec)
+                    with hwmc.HullWhiteEngine(ps, device=local_rank) as es:
+                        Ps, fs = hwmc.analytic_curve(ps)
+                        es.load_market_data(Ps, fs)
+                        ent = {}
+                        for kname, fn_, steps_, geo_name in (
+                                ("zbc", lambda: es.simulate_ZBC_control_variate(nS, 1234), 2000, "zbc"),
+                                ("curve", lambda: es.simulate_zcb(nS, 1234), 4000, "zcb_blocked")):
+                            fn_()                                                   # one untimed launch (43..100 ms: the clocks settle)
+                            es.profile_enable(3)
+                            for _ in range(3):
+                                fn_()
+                            msl = [float(x) for x in es.profile_read(3)]
+                            ms_ = float(np.median(msl))
+                            mhz_ = clock_of(es)
+                            g_ = es.launch_geometry(geo_name, nS)
+                            bytes_ = g_["partial_bytes"] + (5 if kname == "zbc" else ps.n_mat) * 8
+                            loop = ("zbc_" + prec) if kname == "zbc" else ("curve_%s_p4" % prec)
+                            ent[kname] = {"kernel_ms": ms_, "kernel_ms_all": msl, "value": (2 * nS / ms_) / 1000.0, "unit": "M paths/s",
+                                          "thread_steps_per_sec": nS * steps_ / (ms_ * 1e-3),
+                                          "hbm": {"algorithmic_bytes_per_launch": bytes_, "achieved_GBps": bytes_ / (ms_ * 1e-3) / 1e9,
+                                                  "frac": bytes_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                                          "valu": valu_of(ms_, nS, steps_, mhz_, loop), "launch_geometry": g_}
+                        stress[prec] = ent
+                stress["f64_over_f32"] = {k: stress["f64"][k]["kernel_ms"] / stress["f32"][k]["kernel_ms"] for k in ("zbc", "curve")}
+                extras["stress"] = stress
+                respin()
         # strong-scaling reference: the N > 1 workload (2^total_log2 pairs per step) on this ONE GPU, same pipelining
         nref = 1 << a.total_log2
         if a.scaling == "strong" and nref != shard_n and a.stepper == "superposed":
@@ -754,10 +897,11 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "launch_geometry": geo,
                          "note": "stateless Philox: the path kernel has ~0 algorithmic HBM traffic; the binding roof is VALU issue (see valu)"},
             "valu": {"bound": "valu-issue",
-                     "how": "bound = shader-clock cycles per Philox block per SIMD of the production loop's own instruction stream with its "
-                            "data dependencies removed, fastest of all orderings and occupancies tried (tools/mix_bound.hip, generated from "
-                            "the gfx950 listing by tools/gen_mix_bound.py); achieved = launch time x in-kernel clock x SIMDs / pair-blocks, "
-                            "everything a launch does included; frac = bound / achieved, <= 1 by construction",
+                     "how": "bound = measured dependency-free rate of the production ordering: shader-clock cycles per Philox block per SIMD of the "
+                            "production loop's own instruction stream with its data dependencies removed, fastest of the orderings and occupancies "
+                            "tried (tools/mix_bound.hip, generated from the gfx950 listing by tools/gen_mix_bound.py) -- a loop-overhead reference, "
+                            "not a proven floor (that is exclusive_classes_floor); achieved = launch time x in-kernel clock x SIMDs / pair-blocks, "
+                            "everything a launch does included; frac = bound / achieved",
                      "instr_per_4_steps": vm,
                      "bound_cycles_per_block": bcyc,
                      "bound_source": use_bound["source"] if use_bound else None,

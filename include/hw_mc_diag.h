@@ -67,7 +67,7 @@ int  hw_profile_spans(hw_ctx* ctx, hw_ctx* ref, float* start_ms, float* end_ms, 
  * kernel writes (the algorithmic HBM traffic of a launch).  Any output pointer may be NULL. */
 int  hw_get_launch_geometry(hw_ctx* ctx, const char* kernel, int64_t n_units, int32_t* block, int32_t* grid,
                             int32_t* iters, int64_t* partial_bytes);
-/* Shader clock (MHz) the chip held during the last profiled superposed-ZBC launch, from an
+/* Shader clock (MHz) the chip held during the last profiled superposed-ZBC or blocked-curve launch, from an
  * in-kernel s_memtime / s_memrealtime probe in workgroup 0 (read after the launch completed). */
 int  hw_profile_clock(hw_ctx* ctx, double* shader_mhz);
 

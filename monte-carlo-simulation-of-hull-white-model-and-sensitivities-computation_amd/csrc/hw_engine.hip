@@ -515,6 +515,7 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
         a.e2_d = k.e * k.e;                                     // REAL = double: from the double e
         a.c1_d = cz / (1.0 - k.e);
         a.c2_d = cz * (k.e / (1.0 - k.e) + 0.5);
+        a.clk = c->prof_cap > 0 ? c->d_clk : nullptr;
         const size_t lds = (size_t)(g.block / 64) * hwk::maturity_groups(n_mat) * hwk::kWave * sizeof(double);
         if (lds > 64 * 1024)
             return fail(HW_E_INVALID, "n_mat = %d needs %zu B of LDS per workgroup at block size %d (limit 65536): use a smaller block", n_mat, lds, g.block);
@@ -1164,7 +1165,7 @@ int hw_profile_clock(hw_ctx* c, double* shader_mhz)
     HIP_TRY(hipSetDevice(c->device));
     unsigned long long h[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(h, c->d_clk, sizeof h, hipMemcpyDeviceToHost));
-    if (h[3] <= h[1]) return fail(HW_E_INVALID, "no clock probe recorded (profile a superposed ZBC launch first)");
+    if (h[3] <= h[1]) return fail(HW_E_INVALID, "no clock probe recorded (profile a superposed ZBC or a blocked curve launch first)");
     // s_memtime ticks at the shader clock, s_memrealtime at a constant 100 MHz
     *shader_mhz = (double)(h[2] - h[0]) / (double)(h[3] - h[1]) * 100.0;
     return HW_OK;

@@ -1274,6 +1274,7 @@ struct ZcbBlockedArgs {
     float e, e2, c1, c2;
     unsigned long long* stamps;     // nullptr, or the timeline buffer (WorkgroupStamp)
     double e2_d, c1_d, c2_d;        // REAL = double: the same constants in double (e^2, c1, c2 from the double e)
+    unsigned long long* clk;        // optional: workgroup 0 stores {s_memtime, s_memrealtime} at entry and exit (as ZbcArgs::clk)
 };
 
 // REAL = double (the double engine): the state (y, W) is carried in double -- the two half-block inputs s (e sin + cos)
@@ -1289,6 +1290,11 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
     extern __shared__ double s_tiles[];                // [nwaves][groups][64], see MaturityTree
     WorkgroupStamp stamp;
     stamp.begin(a.stamps);
+    const bool clk_probe = a.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;   // diagnostic: the clock this launch ran at
+    if (clk_probe) {
+        a.clk[0] = __builtin_amdgcn_s_memtime();
+        a.clk[1] = __builtin_amdgcn_s_memrealtime();
+    }
     const int wave = threadIdx.x >> 6;
     const int nwaves = (blockDim.x + kWave - 1) >> 6;
     const int groups = maturity_groups(a.n_mat);
@@ -1401,6 +1407,10 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
         else blocks(std::false_type{});
         HWK_SETPRIO(0);
         slots.finish(a.n_mat);
+    }
+    if (clk_probe) {
+        a.clk[2] = __builtin_amdgcn_s_memtime();
+        a.clk[3] = __builtin_amdgcn_s_memrealtime();
     }
     __syncthreads();
     maturity_tiles_to_partials<HWK_MATURITY_TREE != 0>(s_tiles, nwaves, a.n_mat, partials);
