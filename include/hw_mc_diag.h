@@ -67,9 +67,13 @@ int  hw_profile_spans(hw_ctx* ctx, hw_ctx* ref, float* start_ms, float* end_ms, 
  * kernel writes (the algorithmic HBM traffic of a launch).  Any output pointer may be NULL. */
 int  hw_get_launch_geometry(hw_ctx* ctx, const char* kernel, int64_t n_units, int32_t* block, int32_t* grid,
                             int32_t* iters, int64_t* partial_bytes);
-/* Shader clock (MHz) the chip held during the last profiled superposed-ZBC or blocked-curve launch, from an
- * in-kernel s_memtime / s_memrealtime probe in workgroup 0 (read after the launch completed). */
+/* Shader clock (MHz) the chip held during the last profiled superposed-ZBC or blocked-curve launch, from in-kernel
+ * s_memtime / s_memrealtime probes in up to 16 workgroups spread evenly over the grid (= along the launch, workgroups being
+ * dispatched in index order): the time-weighted mean over the probing workgroups' lifetimes (read after the launch completed). */
 int  hw_profile_clock(hw_ctx* ctx, double* shader_mhz);
+/* The individual probes of that launch: clock (MHz) of each probing workgroup and its entry / exit time in microseconds
+ * after the first probe's entry (any output pointer may be NULL); *n_out = how many probed. */
+int  hw_profile_clock_samples(hw_ctx* ctx, double* mhz, double* start_us, double* end_us, int32_t cap, int32_t* n_out);
 
 #ifdef __cplusplus
 }

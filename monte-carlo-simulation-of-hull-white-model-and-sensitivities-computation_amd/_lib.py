@@ -103,6 +103,7 @@ DIAG_SIGNATURES = {
     "hw_profile_enable": (C.c_int, [_CTX, C.c_int32]),
     "hw_profile_read": (C.c_int, [_CTX, _FP, C.c_int32, C.POINTER(C.c_int32)]),
     "hw_profile_clock": (C.c_int, [_CTX, _DP]),
+    "hw_profile_clock_samples": (C.c_int, [_CTX, _DP, _DP, _DP, C.c_int32, C.POINTER(C.c_int32)]),
     "hw_profile_spans": (C.c_int, [_CTX, _CTX, _FP, _FP, C.c_int32, C.POINTER(C.c_int32)]),
     "hw_get_launch_geometry": (C.c_int, [_CTX, C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                          C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),

@@ -100,7 +100,7 @@ struct hw_ctx {
     double* d_scale = nullptr;        // per-column scale for the curve (n_mat doubles)
     float* d_drift = nullptr;         // float table for the reference stepper / sample paths
     unsigned* d_ticket = nullptr;     // grid_sum_finish ticket counter (self re-arming)
-    unsigned long long* d_clk = nullptr;  // clock probe of the last superposed ZBC launch (4 words)
+    unsigned long long* d_clk = nullptr;  // clock probes of the last profiled superposed-ZBC / blocked-curve launch (kClkProbes x 4 words)
     // launch knobs
     int block_size = 0;               // 0 = automatic (see geometry())
     int max_blocks_per_cu = 0;        // in units of block_size-thread workgroups; 0 = default
@@ -285,6 +285,20 @@ int effective_ilp(const hw_ctx* c, int64_t n_units, int n_steps, double e, int n
     return n_units >= (int64_t)min_fills * 2048 * c->prop.multiProcessorCount ? 2 : 1;
 }
 
+// Arm the clock probes of a profiled launch: zero the slots (stream order) and spread kClkProbes probing workgroups over the grid.
+int arm_clock_probe(hw_ctx* c, hipStream_t st, int grid, unsigned long long** clk, uint32_t* shift)
+{
+    *clk = nullptr;
+    *shift = 0;
+    if (c->prof_cap <= 0) return HW_OK;
+    HIP_TRY(hipMemsetAsync(c->d_clk, 0, hwk::kClkProbes * 4 * sizeof(unsigned long long), st));
+    uint32_t sh = 0;
+    while (((int64_t)hwk::kClkProbes << (sh + 1)) <= (int64_t)grid) sh++;
+    *clk = c->d_clk;
+    *shift = sh;
+    return HW_OK;
+}
+
 // second launch of the default two-launch finish (no-op when the kernel finished in-launch)
 int finish_columns(hw_ctx* c, hipStream_t st, int rows, int ncol, double* d_out, int n_groups = 1, bool finished_in_kernel = false)
 {
@@ -369,7 +383,8 @@ int launch_zbc_superposed(hw_ctx* c, const hw_zbc_request* r, int n_steps_S1, co
     a.iters = g.iters;
     a.e = (REAL)sc[0].k.e;
     for (int k = 0; k < NSCEN; k++) a.sc[k] = make_scen<REAL>(sc[k], r->K);
-    a.clk = c->prof_cap > 0 ? c->d_clk : nullptr;
+    rc = arm_clock_probe(c, st, total_grid, &a.clk, &a.clk_shift);
+    if (rc) return rc;
     a.blocks_per_run = (uint32_t)g.grid;
     a.seed_stride = seed_stride;
     // (measured and rejected, profiles/r03_sync_call_probe.txt: finishing IN the kernel for the polled synchronous calls -- no
@@ -515,7 +530,8 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
         a.e2_d = k.e * k.e;                                     // REAL = double: from the double e
         a.c1_d = cz / (1.0 - k.e);
         a.c2_d = cz * (k.e / (1.0 - k.e) + 0.5);
-        a.clk = c->prof_cap > 0 ? c->d_clk : nullptr;
+        rc = arm_clock_probe(c, st, g.grid, &a.clk, &a.clk_shift);
+        if (rc) return rc;
         const size_t lds = (size_t)(g.block / 64) * hwk::maturity_groups(n_mat) * hwk::kWave * sizeof(double);
         if (lds > 64 * 1024)
             return fail(HW_E_INVALID, "n_mat = %d needs %zu B of LDS per workgroup at block size %d (limit 65536): use a smaller block", n_mat, lds, g.block);
@@ -734,8 +750,8 @@ int hw_create(const hw_params* p, int device, hw_ctx** out)
     if (const char* m = getenv("HWMC_SPIN_WAIT")) c->spin_wait = atoi(m) ? 1 : 0;
     if (e == hipSuccess) e = hipMalloc(&c->d_scale, (size_t)p->n_mat * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&c->d_drift, (size_t)p->n_steps * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&c->d_clk, 64);
-    if (e == hipSuccess) e = hipMemset(c->d_clk, 0, 64);
+    if (e == hipSuccess) e = hipMalloc(&c->d_clk, hwk::kClkProbes * 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(c->d_clk, 0, hwk::kClkProbes * 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&c->d_ticket, 9 * hwk::kTicketStride * sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(c->d_ticket, 0, 9 * hwk::kTicketStride * sizeof(unsigned));
     if (const char* m = getenv("HWMC_SINGLE_LAUNCH")) c->single_launch = atoi(m) ? 1 : 0;
@@ -1159,15 +1175,43 @@ int hw_get_launch_geometry(hw_ctx* c, const char* kernel, int64_t n_units, int32
     return HW_OK;
 }
 
+int hw_profile_clock_samples(hw_ctx* c, double* mhz, double* start_us, double* end_us, int32_t cap, int32_t* n_out)
+{
+    if (!c || !n_out) return fail(HW_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long h[hwk::kClkProbes * 4];
+    HIP_TRY(hipMemcpy(h, c->d_clk, sizeof h, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (int j = 0; j < hwk::kClkProbes; j++)
+        if (h[4 * j + 3] > h[4 * j + 1]) t0 = std::min(t0, h[4 * j + 1]);
+    int n = 0;
+    for (int j = 0; j < hwk::kClkProbes && n < cap; j++) {
+        if (h[4 * j + 3] <= h[4 * j + 1]) continue;               // this workgroup did not probe (grid smaller than kClkProbes)
+        // s_memtime ticks at the shader clock, s_memrealtime at a constant 100 MHz
+        if (mhz) mhz[n] = (double)(h[4 * j + 2] - h[4 * j]) / (double)(h[4 * j + 3] - h[4 * j + 1]) * 100.0;
+        if (start_us) start_us[n] = (double)(h[4 * j + 1] - t0) / 100.0;
+        if (end_us) end_us[n] = (double)(h[4 * j + 3] - t0) / 100.0;
+        n++;
+    }
+    *n_out = n;
+    return HW_OK;
+}
+
 int hw_profile_clock(hw_ctx* c, double* shader_mhz)
 {
     if (!c || !shader_mhz) return fail(HW_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    unsigned long long h[4] = {0, 0, 0, 0};
+    unsigned long long h[hwk::kClkProbes * 4];
     HIP_TRY(hipMemcpy(h, c->d_clk, sizeof h, hipMemcpyDeviceToHost));
-    if (h[3] <= h[1]) return fail(HW_E_INVALID, "no clock probe recorded (profile a superposed ZBC or a blocked curve launch first)");
-    // s_memtime ticks at the shader clock, s_memrealtime at a constant 100 MHz
-    *shader_mhz = (double)(h[2] - h[0]) / (double)(h[3] - h[1]) * 100.0;
+    // time-weighted mean over the probing workgroups: they are spread over the grid, i.e. along the launch
+    double cyc = 0.0, real = 0.0;
+    for (int j = 0; j < hwk::kClkProbes; j++)
+        if (h[4 * j + 3] > h[4 * j + 1]) {
+            cyc += (double)(h[4 * j + 2] - h[4 * j]);
+            real += (double)(h[4 * j + 3] - h[4 * j + 1]);
+        }
+    if (!(real > 0.0)) return fail(HW_E_INVALID, "no clock probe recorded (profile a superposed ZBC or a blocked curve launch first)");
+    *shader_mhz = cyc / real * 100.0;
     return HW_OK;
 }
 

@@ -421,6 +421,36 @@ struct WorkgroupStamp {
     }
 };
 
+// Optional clock probe (diagnostic; hw_profile_clock*): up to kClkProbes workgroups spread evenly over the grid -- workgroup
+// j << shift, j < kClkProbes -- store {s_memtime (shader clock), s_memrealtime (100 MHz)} at their entry and exit into
+// clk[4 j .. 4 j + 3].  Workgroups are dispatched in index order, so the probes sample the clock along the whole launch: ONE
+// probe in workgroup 0 (rounds 1-3) saw only the first slot of a launch whose grid is larger than the chip, and the clock
+// of a 40-100 ms launch is not constant (tools/labs/clock_vs_duration.py).  All conditions are wave-uniform scalars.
+constexpr int kClkProbes = 16;
+struct ClockProbe {
+    __device__ static __forceinline__ bool mine(const unsigned long long* clk, uint32_t shift, uint32_t& j)
+    {
+        j = blockIdx.x >> shift;
+        return clk != nullptr && (j << shift) == blockIdx.x && j < (uint32_t)kClkProbes && threadIdx.x == 0;
+    }
+    __device__ static __forceinline__ void begin(unsigned long long* clk, uint32_t shift)
+    {
+        uint32_t j;
+        if (mine(clk, shift, j)) {
+            clk[4 * j + 0] = __builtin_amdgcn_s_memtime();
+            clk[4 * j + 1] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+    __device__ static __forceinline__ void end(unsigned long long* clk, uint32_t shift)
+    {
+        uint32_t j;
+        if (mine(clk, shift, j)) {
+            clk[4 * j + 2] = __builtin_amdgcn_s_memtime();
+            clk[4 * j + 3] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+};
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -1008,7 +1038,8 @@ struct ZbcArgs {
     int32_t n_steps, iters;
     REAL e;
     ZbcScen<REAL> sc[NSCEN];
-    unsigned long long* clk;   // optional: workgroup 0 stores {s_memtime, s_memrealtime} at entry and exit
+    unsigned long long* clk;   // optional clock probe (ClockProbe): 4 words per probing workgroup
+    uint32_t clk_shift;        // probing workgroups: j << clk_shift, j < kClkProbes
     unsigned long long* stamps; // optional: every workgroup's entry/exit s_memrealtime (WorkgroupStamp)
     // several independent runs in one launch (the 20-run validation, 2_option:210-468): workgroup b belongs
     // to run b / blocks_per_run and uses seed + run * seed_stride.  One run: blocks_per_run = gridDim.x.
@@ -1024,12 +1055,7 @@ zbc_superposed_kernel(const ZbcArgs<REAL, NSCEN> a, double* __restrict__ partial
     __shared__ double smem[kMaxWaves * 5 * NSCEN];
     WorkgroupStamp wg_stamp;
     wg_stamp.begin(a.stamps);
-    // clock probe (diagnostic only; the stamps go to a buffer nothing else reads)
-    const bool stamp = a.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
-    if (stamp) {
-        a.clk[0] = __builtin_amdgcn_s_memtime();
-        a.clk[1] = __builtin_amdgcn_s_memrealtime();
-    }
+    ClockProbe::begin(a.clk, a.clk_shift);          // diagnostic only; the stamps go to a buffer nothing else reads
     const uint32_t run = blockIdx.x / a.blocks_per_run;
     const uint32_t block_in_run = blockIdx.x - run * a.blocks_per_run;
     const PhiloxKey key = philox_key(a.seed + (uint64_t)run * a.seed_stride);
@@ -1077,10 +1103,7 @@ zbc_superposed_kernel(const ZbcArgs<REAL, NSCEN> a, double* __restrict__ partial
             }
         }
     }
-    if (stamp) {
-        a.clk[2] = __builtin_amdgcn_s_memtime();
-        a.clk[3] = __builtin_amdgcn_s_memrealtime();
-    }
+    ClockProbe::end(a.clk, a.clk_shift);
     grid_sum_finish<5 * NSCEN>(acc, smem, partials, ticket, out);
     // after the cross-wave finish (its barrier): the end of the workgroup's LAST wave.  (Stamped before it, thread 0 reports
     // when wave 0 -- the oldest of the workgroup, which the issue arbiter favours -- finished its paths: up to ~10 us early.)
@@ -1274,7 +1297,8 @@ struct ZcbBlockedArgs {
     float e, e2, c1, c2;
     unsigned long long* stamps;     // nullptr, or the timeline buffer (WorkgroupStamp)
     double e2_d, c1_d, c2_d;        // REAL = double: the same constants in double (e^2, c1, c2 from the double e)
-    unsigned long long* clk;        // optional: workgroup 0 stores {s_memtime, s_memrealtime} at entry and exit (as ZbcArgs::clk)
+    unsigned long long* clk;        // optional clock probe (ClockProbe), as ZbcArgs::clk / clk_shift
+    uint32_t clk_shift;
 };
 
 // REAL = double (the double engine): the state (y, W) is carried in double -- the two half-block inputs s (e sin + cos)
@@ -1290,11 +1314,7 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
     extern __shared__ double s_tiles[];                // [nwaves][groups][64], see MaturityTree
     WorkgroupStamp stamp;
     stamp.begin(a.stamps);
-    const bool clk_probe = a.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;   // diagnostic: the clock this launch ran at
-    if (clk_probe) {
-        a.clk[0] = __builtin_amdgcn_s_memtime();
-        a.clk[1] = __builtin_amdgcn_s_memrealtime();
-    }
+    ClockProbe::begin(a.clk, a.clk_shift);             // diagnostic: the clock this launch ran at
     const int wave = threadIdx.x >> 6;
     const int nwaves = (blockDim.x + kWave - 1) >> 6;
     const int groups = maturity_groups(a.n_mat);
@@ -1408,10 +1428,7 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
         HWK_SETPRIO(0);
         slots.finish(a.n_mat);
     }
-    if (clk_probe) {
-        a.clk[2] = __builtin_amdgcn_s_memtime();
-        a.clk[3] = __builtin_amdgcn_s_memrealtime();
-    }
+    ClockProbe::end(a.clk, a.clk_shift);
     __syncthreads();
     maturity_tiles_to_partials<HWK_MATURITY_TREE != 0>(s_tiles, nwaves, a.n_mat, partials);
     stamp.end(a.stamps);

@@ -1,4 +1,5 @@
-// mix_bound.hip -- the issue bound of the ZBC hot loop's instruction mix, measured on the GPU it runs on.
+// mix_bound.hip -- the issue bound of the production loops' instruction mixes (float ZBC/Vega loop, double ZBC loop, curve loop),
+// measured on the GPU they run on.
 //
 // tools/gen_mix_bound.py turns the production loop (gfx950 listing of csrc/hw_engine.hip) into dependency-free twins
 // (tools/mix_bound_body.inc): same opcodes, same order, same operand classes, same s_setprio choreography, but no
@@ -40,8 +41,10 @@
     "s_mov_b32 s38, 0\n\t" \
     "s_memrealtime s[80:81]\n\ts_memtime s[76:77]\n\ts_waitcnt lgkmcnt(0)\n\t" \
     "1:\n\t"
-#define MIX_EPILOGUE \
-    "s_add_u32 s38, s38, 1\n\ts_and_b32 s39, s38, 15\n\ts_cmp_lg_u32 s39, 0\n\ts_cbranch_scc1 1b\n\t" \
+// MASK: the deadline is looked at every (MASK + 1) trips -- 15 for the one- and two-block loops; 0 for the curve twins, whose
+// trip is a whole period of sixteen maturities (40 or 640 pair-blocks)
+#define MIX_EPILOGUE(MASK) \
+    "s_add_u32 s38, s38, 1\n\ts_and_b32 s39, s38, " #MASK "\n\ts_cmp_lg_u32 s39, 0\n\ts_cbranch_scc1 1b\n\t" \
     "s_memrealtime s[82:83]\n\ts_waitcnt lgkmcnt(0)\n\t" \
     "s_sub_u32 s84, s82, %[dlo]\n\ts_subb_u32 s85, s83, %[dhi]\n\t" \
     "s_cmp_lt_i32 s85, 0\n\ts_cbranch_scc1 1b\n\t" \
@@ -53,12 +56,12 @@
 
 // out[3 w] = (trips << 32) | elapsed shader cycles, out[3 w + 1], out[3 w + 2] = s_memrealtime (100 MHz, one counter for the
 // whole chip) when the wave started / ended
-#define MIX_KERNEL(NAME)                                                                                              \
+#define MIX_KERNEL(NAME, MASK)                                                                                        \
     __global__ void __launch_bounds__(512) mix_##NAME(unsigned long long* out, unsigned dlo, unsigned dhi, float seed)                \
     {                                                                                                                 \
         const float in = seed + 0.001f * (float)(threadIdx.x & 63);                                                   \
         unsigned clo, chi, rlo, rhi, elo, ehi;                                                                        \
-        asm volatile(MIX_PROLOGUE MIX_BODY_##NAME MIX_EPILOGUE                                                        \
+        asm volatile(MIX_PROLOGUE MIX_BODY_##NAME MIX_EPILOGUE(MASK)                                                  \
                      : [clo] "=s"(clo), [chi] "=s"(chi), [rlo] "=s"(rlo), [rhi] "=s"(rhi), [elo] "=s"(elo), [ehi] "=s"(ehi) \
                      : [in] "v"(in), [dlo] "s"(dlo), [dhi] "s"(dhi)                                                                  \
                      : MIX_HARNESS_CLOBBERS, MIX_CLOBBERS_##NAME);                                                    \
@@ -70,13 +73,14 @@
         }                                                                                                             \
     }
 
-#define MIX_DEFINE(NAME, DF, FM) MIX_KERNEL(NAME)
+#define MIX_DEFINE(NAME, DF, FM, FAMILY, MASK, WSCALE) MIX_KERNEL(NAME, MASK)
 MIX_VARIANTS(MIX_DEFINE)
 
 typedef void (*Kern)(unsigned long long*, unsigned, unsigned, float);
 
 __global__ void now_kernel(unsigned long long* out) { out[0] = __builtin_amdgcn_s_memrealtime(); }
-struct Variant { const char* name; Kern k; int blocks; bool dependency_free; bool full_mix; };
+struct Variant { const char* name; Kern k; int blocks; bool dependency_free; bool full_mix; const char* family; int window_scale; };
+struct Family { std::string name, bound_at; double bound = 1e30, real = 1e30; };
 
 int main(int argc, char** argv)
 {
@@ -92,7 +96,7 @@ int main(int argc, char** argv)
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
-#define MIX_ROW(NAME, DF, FM) {#NAME, mix_##NAME, MIX_BLOCKS_##NAME, DF != 0, FM != 0},
+#define MIX_ROW(NAME, DF, FM, FAMILY, MASK, WSCALE) {#NAME, mix_##NAME, MIX_BLOCKS_##NAME, DF != 0, FM != 0, FAMILY, WSCALE},
     const Variant vars[] = { MIX_VARIANTS(MIX_ROW) };
     std::vector<int> occs = {4, 6, 8};                     // waves per SIMD
     if (only_occ) occs.assign(1, only_occ);
@@ -110,11 +114,18 @@ int main(int argc, char** argv)
     int mhz_n = 0;
     std::string bound_at, rows;
     // warm the clocks: ~0.15 s of the production mix
-    auto deadline = [&]() -> unsigned long long {          // the chip's own 100 MHz counter now + the window (+ 30 us for the launch)
+    auto deadline = [&](int scale = 1) -> unsigned long long {   // the chip's own 100 MHz counter now + the window (+ 30 us for the launch)
         unsigned long long now = 0;
         hipLaunchKernelGGL(now_kernel, dim3(1), dim3(1), 0, 0, d_out);
         CHECK(hipMemcpy(&now, d_out, sizeof now, hipMemcpyDeviceToHost));
-        return now + (unsigned long long)budget + 3000ull;
+        return now + (unsigned long long)budget * (unsigned long long)scale + 3000ull;
+    };
+    std::vector<Family> fams;
+    auto fam_of = [&](const char* nm) -> Family& {
+        for (Family& f : fams) if (f.name == nm) return f;
+        fams.emplace_back();
+        fams.back().name = nm;
+        return fams.back();
     };
     for (int i = 0; i < 60; i++) {
         const unsigned long long dl = deadline();
@@ -134,7 +145,7 @@ int main(int argc, char** argv)
             const size_t waves = (size_t)grid * 8;
             double best = 1e30, best_tmin = 0, best_tmax = 0, best_mhz = 0, best_ratio = 0, best_stagger = 0;
             for (int rep = 0; rep < 5; rep++) {
-                const unsigned long long dl = deadline();
+                const unsigned long long dl = deadline(v.window_scale);
                 hipLaunchKernelGGL(v.k, dim3(grid), dim3(512), 0, 0, d_out, (unsigned)dl, (unsigned)(dl >> 32), 0.3f + 0.01f * rep);
                 CHECK(hipGetLastError());
                 CHECK(hipMemcpy(h.data(), d_out, waves * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -154,7 +165,7 @@ int main(int argc, char** argv)
                 const double per_block = (double)cus * 4.0 * span / (trips * v.blocks);
                 if (per_block < best) {
                     best = per_block; best_tmin = tmin; best_tmax = tmax; best_mhz = mhz;
-                    best_ratio = (double)(last - first) / (double)budget; best_stagger = (double)(latest_start - first) / 100.0;
+                    best_ratio = (double)(last - first) / ((double)budget * v.window_scale); best_stagger = (double)(latest_start - first) / 100.0;
                 }
             }
             mhz_sum += best_mhz; mhz_n++;
@@ -163,7 +174,13 @@ int main(int argc, char** argv)
             snprintf(row, sizeof row, "%s{\"variant\": \"%s\", \"waves_per_simd\": %d, \"cycles_per_block\": %.3f, \"trips_min\": %.0f, \"trips_max\": %.0f, \"shader_mhz\": %.1f, \"span_over_window\": %.4f, \"last_start_us\": %.1f}",
                      rows.empty() ? "" : ", ", v.name, occ, best, best_tmin, best_tmax, best_mhz, best_ratio, best_stagger);
             rows += row;
-            if (v.dependency_free && v.full_mix && best_ratio < 1.05 /* span ~ window: the waves really ran side by side */ && best < bound) { bound = best; bound_at = std::string(v.name) + " @ " + std::to_string(occ) + " waves/SIMD"; }
+            const bool zbc32 = !strcmp(v.family, "zbc_f32");
+            if (zbc32 && v.dependency_free && v.full_mix && best_ratio < 1.05 /* span ~ window: the waves really ran side by side */ && best < bound) { bound = best; bound_at = std::string(v.name) + " @ " + std::to_string(occ) + " waves/SIMD"; }
+            if (v.full_mix) {
+                Family& f = fam_of(v.family);
+                if (v.dependency_free && best_ratio < 1.05 && best < f.bound) { f.bound = best; f.bound_at = std::string(v.name) + " @ " + std::to_string(occ) + " waves/SIMD"; }
+                if (!v.dependency_free) f.real = std::min(f.real, best);
+            }
             if (!strcmp(v.name, "REAL1")) real1 = std::min(real1, best);
             if (!strcmp(v.name, "REAL2")) real2 = std::min(real2, best);
             if (!strcmp(v.name, "EXCL")) excl = std::min(excl, best);
@@ -176,15 +193,29 @@ int main(int argc, char** argv)
                "\"bound_cycles_per_block\": %.3f, \"bound_at\": \"%s\", "
                "\"exclusive_classes_nominal_floor\": %d, \"exclusive_classes_measured\": %.3f, \"single_rate_only_measured\": %.3f, "
                "\"nominal_serial_model\": %d, \"real_loop_cycles_per_block\": {\"one_pair_per_thread\": %.3f, \"two_pairs_per_thread\": %.3f}, "
-               "\"shader_mhz_mean\": %.1f, \"rows\": [%s]}\n",
+               "\"shader_mhz_mean\": %.1f, \"loops\": {",
                prop.gcnArchName, cus, budget, f, hf, q, bound, bound_at.c_str(), 4 * hf + 8 * q, excl, simple, 2 * f + 4 * hf + 8 * q,
-               real1, real2, mhz_sum / mhz_n, rows.c_str());
+               real1, real2, mhz_sum / mhz_n);
+        // every production loop with a twin: its bound (fastest dependency-free full mix of the family) and, where the loop can run
+        // verbatim in this harness (straight-line loops), its own rate here
+        for (size_t i = 0; i < fams.size(); i++) {
+            printf("%s\"%s\": {\"bound_cycles_per_block\": %.3f, \"bound_at\": \"%s\", \"real_loop_cycles_per_block\": ", i ? ", " : "",
+                   fams[i].name.c_str(), fams[i].bound, fams[i].bound_at.c_str());
+            if (fams[i].real < 1e29) printf("%.3f}", fams[i].real); else printf("null}");
+        }
+        printf("}, \"rows\": [%s]}\n", rows.c_str());
     } else {
         printf("\nBOUND (fastest dependency-free full mix): %.2f cycles per block  [%s]\n", bound, bound_at.c_str());
         printf("exclusive classes alone (16 mad + 4 cvt + 8 transcendental): nominal 4/4/8 floor %d, measured %.2f\n", 4 * hf + 8 * q, excl);
         printf("single-rate instructions alone (%d): nominal %d, measured %.2f\n", f, 2 * f, simple);
         printf("nominal serial model 2/4/8: %d\n", 2 * f + 4 * hf + 8 * q);
         printf("production loop verbatim in this harness: %.2f (one pair per thread), %.2f (two pairs)\n", real1, real2);
+        printf("\nper production loop (cycles per pair-block per SIMD):\n");
+        for (const Family& fm : fams) {
+            printf("  %-14s bound %.2f  [%s]", fm.name.c_str(), fm.bound, fm.bound_at.c_str());
+            if (fm.real < 1e29) printf("   the loop verbatim in this harness: %.2f", fm.real);
+            printf("\n");
+        }
     }
     CHECK(hipFree(d_out));
     return 0;
