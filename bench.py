@@ -285,6 +285,13 @@ def main():
             else:
                 dist.init_process_group("nccl", device_id=dev)
     cdev = "cpu" if rehearsal else dev                 # where the small control tensors of the collectives live
+    # a second, host-side group (gloo) for the side measurement "the same pricing call with the sums added on the host"
+    host_group = None
+    if dist_on and not rehearsal:
+        try:
+            host_group = dist.new_group(backend="gloo")
+        except Exception:                              # (a build of torch without gloo: the side measurement is skipped)
+            host_group = None
 
     import numpy as np
     import hwmc
@@ -433,7 +440,7 @@ def main():
     # ---- the timed regions: EXACTLY K steps each, barrier + synchronize on both sides -----------------------------
     # One HIP event pair brackets the K launches of a region: recorded on streams[0] before the first launch and, after
     # streams[0] has been made to wait for the other streams, behind the last one.
-    elapsed_regions, region_ms_events = [], []
+    elapsed_regions, region_ms_events, region_wall_start = [], [], []
     r_done = 0
     while True:
         if R > 0 and r_done >= R:
@@ -442,6 +449,7 @@ def main():
         ev1 = torch.cuda.Event(enable_timing=True)
         works = []
         fence()
+        region_wall_start.append(time.time())              # (one node, one host clock: comparable across ranks -> multi_gpu.launch_skew)
         t0 = time.perf_counter()
         ev0.record(streams[0])
         for i in range(K):
@@ -555,11 +563,45 @@ def main():
         allreduce_alone_ms = float(np.median(tt))
         fence()
     per_rank_kernel_ms = None
+    seen = skew = compute_only_ms = single_call_host_ms = None
     if dist_on:
         mine = torch.tensor([float(np.mean(kernel_ms_isolated))], dtype=torch.float64, device=cdev)
         allk = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allk, mine)
         per_rank_kernel_ms = [float(x.item()) for x in allk]
+        # what an N-GPU line needs to check itself (hwmc.parallel.check_scaling_lines): who took part, how far apart the
+        # ranks left the barrier, and what the collectives cost on top of the same K steps without them
+        seen = hwmc.parallel.world_size_seen(cdev)
+        skew = hwmc.parallel.launch_skew(region_wall_start[:R_side], cdev)
+        co = []
+        for _ in range(R_side):                            # the timed region again, same alternation, NO all-reduce
+            fence()
+            tc = time.perf_counter()
+            for i in range(K):
+                enqueue(i, 1234 + 12345 * i, scratch[i])
+            torch.cuda.synchronize()
+            co.append((time.perf_counter() - tc) * 1e3 / K)
+            fence()
+        tco = torch.tensor(co, dtype=torch.float64, device=cdev)
+        dist.all_reduce(tco, op=dist.ReduceOp.MAX)
+        compute_only_ms = float(np.median(tco.cpu().numpy()))
+        # one sharded pricing call with the five sums added on the HOST (device -> host copy, gloo all-reduce) instead of RCCL
+        hg = None if rehearsal else host_group
+        if rehearsal or hg is not None:
+            tt = []
+            for i in range(min(K, 10)):
+                dist.barrier()
+                torch.cuda.synchronize()
+                tc = time.perf_counter()
+                enqueue(0, 1234 + 12345 * i, out[0], n_streams=1)
+                torch.cuda.synchronize()
+                tmp = out[0].cpu()
+                dist.all_reduce(tmp, group=hg)
+                tt.append((time.perf_counter() - tc) * 1e3)
+            th = torch.tensor([float(np.median(tt))], dtype=torch.float64, device=cdev)
+            dist.all_reduce(th, op=dist.ReduceOp.MAX)
+            single_call_host_ms = float(th.item())
+        fence()
 
     extras = {}
     if world == 1 and not a.no_extras and S > 1:
@@ -802,9 +844,14 @@ def main():
                 enqueue(i, 1234 + 12345 * i, scratch[i], n=nref, off=0, n_streams=1)
             torch.cuda.synchronize()
             ref_serial_ms = (time.perf_counter() - tr) * 1e3 / kk
+            ref_sums0 = [float(x) for x in scratch[0].cpu().numpy()]           # seed 1234 = the first timed step of an N-GPU run
+            ref_kernel_ms = float(np.median(isolated_ms(e, lambda: e.simulate_ZBC_control_variate(nref, 1234), 3, pair=False)))
             extras["strong_scaling_reference"] = {
                 "pairs_per_step": nref, "n_gpus": 1, "ms_per_step": ref_ms, "value": (2 * nref / ref_ms) / 1000.0,
-                "serial_ms_per_step": ref_serial_ms, "unit": "M paths/s",
+                "serial_ms_per_step": ref_serial_ms, "kernel_ms": ref_kernel_ms, "unit": "M paths/s",
+                "sums_step0": ref_sums0,
+                "sums_step0_note": "the five sums of the pricing call with seed 1234 over all 2^%d pairs: an N-GPU line's sums_step0 must equal "
+                                   "them to 1e-13 (hwmc.parallel.check_scaling_lines)" % a.total_log2,
                 "note": "the workload bench.py --gpus N > 1 shards (BASELINE configs[3]) run whole on one GPU: divide an N-GPU line's "
                         "ms_per_step into this one's for the strong-scaling factor"}
 
@@ -940,6 +987,14 @@ def main():
         line.update(extras)
         if dist_on:
             line["multi_gpu"] = {"all_reduce": "5 f64 per pricing call" if B == 1 else "5 f64 x %d steps per message" % B,
+                                 "world_size_seen": seen, "launch_skew": skew,
+                                 "compute_only_ms_per_step": compute_only_ms,
+                                 "exposed_allreduce_ms_per_step": ms_per_step - compute_only_ms,
+                                 "exposed_note": "ms_per_step minus the same K steps in the same alternation WITHOUT the all-reduce (MAX over ranks, median of "
+                                                 "%d barrier-bracketed regions): what the collectives add to a step after overlap" % R_side,
+                                 "single_call_host_sum_ms": single_call_host_ms,
+                                 "single_call_host_sum_note": "the same strictly serial pricing call with the five sums copied to the host and added by a gloo "
+                                                              "all-reduce instead of RCCL (MAX over ranks)",
                                  "single_call_ms": single_call_ms,
                                  "single_call_value": (n_eff / single_call_ms) / 1000.0 if single_call_ms else None,
                                  "single_call_note": "one sharded pricing call end to end, strictly serial: launch -> all-reduce -> host synchronises (MAX over ranks)",

@@ -68,3 +68,96 @@ def pricing_workload(n_gpus, scaling="strong", pairs_log2=20, total_log2=24):
     if n_gpus == 1 or scaling == "weak":
         return (1 << pairs_log2) * n_gpus
     return 1 << total_log2
+
+
+# ---- a multi-rank run that checks itself (no 8-GPU node was ever available to the authoring rounds: the first run on
+# ---- one has to tell, from its own output line, whether it priced the right sample set and where its time went) ----------
+def world_size_seen(device="cpu", group=None):
+    """How many ranks really take part: torch's own count and the sum of an all-reduce of ones (a rank that silently
+    dropped out of the collective, or a launcher that started fewer processes than --gpus, shows as a mismatch)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"dist": 1, "allreduce_of_ones": 1}
+    one = torch.ones(1, dtype=torch.float64, device=device)
+    dist.all_reduce(one, group=group)
+    return {"dist": int(dist.get_world_size(group)), "allreduce_of_ones": int(round(float(one.item())))}
+
+
+def gather_floats(values, device="cpu", group=None):
+    """values (a list of floats of the same length on every rank) from all ranks -> [world][len] (rank order)."""
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if not (dist.is_available() and dist.is_initialized()):
+        return [t.tolist()]
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, t, group=group)
+    return [x.tolist() for x in out]
+
+
+def launch_skew(t_start_wall_s, device="cpu", group=None):
+    """Spread of the ranks' host clocks (time.time(): one node, one clock) at the moment each rank began to enqueue a timed
+    region, behind the barrier: what the barrier's own release jitter costs a region of K steps.  Input: this rank's
+    start times, one per region."""
+    rows = gather_floats(t_start_wall_s, device, group)
+    per_region = [max(col) - min(col) for col in zip(*rows)]
+    per_region.sort()
+    med = per_region[len(per_region) // 2] if per_region else 0.0
+    return {"median_ms": med * 1e3, "max_ms": (per_region[-1] if per_region else 0.0) * 1e3, "regions": len(per_region),
+            "how": "max - min over ranks of time.time() when the rank enqueued the first launch of a timed region (same host clock)"}
+
+
+def check_scaling_lines(line1, lineN, rel=1e-13):
+    """Invariants an N-GPU bench line must satisfy against the N = 1 line of the same build (both are bench.py JSON lines).
+    Raises AssertionError naming the violated invariant; returns the scaling report.
+
+      * same metric, dtype, grid and stepper; lineN prices the workload line1 carries as `strong_scaling_reference`
+      * every rank took part: world_size_seen.dist == world_size_seen.allreduce_of_ones == n_gpus
+      * SAME SAMPLE SET: the reduced sums of the first timed step equal the one-GPU sums of the same pricing call to `rel`
+        (subsequence = global pair id: only the order of the float64 additions differs)
+      * value == effective_paths / ms_per_step, and ms_per_step is not below the slowest rank's kernel time
+    The report names what decides between ">= 7x" and "collective exposed": strong_scaling (reference ms / N-GPU ms),
+    compute_scaling (reference kernel ms / slowest rank's kernel ms), exposed_allreduce_ms_per_step, launch_skew."""
+    ref = line1.get("strong_scaling_reference")
+    assert ref, "the N = 1 line carries no strong_scaling_reference (run bench.py without --no-extras)"
+    n = lineN["n_gpus"]
+    assert n > 1 and line1["n_gpus"] == 1, "need an N = 1 and an N > 1 line"
+    for key in ("metric", "unit", "dtype"):
+        assert line1[key] == lineN[key], "lines differ in %s" % key
+    c1, cN = line1["config"], lineN["config"]
+    for key in ("grid_steps", "steps_executed", "stepper", "theta_profile"):
+        assert c1[key] == cN[key], "lines differ in config.%s" % key
+    assert lineN["scaling"] == "strong" and cN["pairs_per_step"] == ref["pairs_per_step"], \
+        "the N-GPU line prices %d pairs per call, the N = 1 reference %d" % (cN["pairs_per_step"], ref["pairs_per_step"])
+    mg = lineN.get("multi_gpu")
+    assert mg, "the N-GPU line has no multi_gpu block"
+    seen = mg["world_size_seen"]
+    assert seen["dist"] == seen["allreduce_of_ones"] == n, "ranks seen %r, line says n_gpus = %d" % (seen, n)
+    assert len(mg["per_rank_kernel_ms"]) == n
+    a, b = lineN["sums_step0"], ref["sums_step0"]
+    assert len(a) == len(b) == 5
+    worst = max(abs(x - y) / max(abs(y), 1e-300) for x, y in zip(a, b))
+    assert worst <= rel, "the N-GPU run did not price the N = 1 sample set: sums_step0 differ by %.3e (relative)" % worst
+    eff = cN["effective_paths"]
+    assert abs(lineN["value"] - eff / lineN["ms_per_step"] / 1000.0) <= 1e-3 * lineN["value"], "value is not effective_paths / ms_per_step"
+    slowest = max(mg["per_rank_kernel_ms"])
+    report = {
+        "n_gpus": n, "sums_step0_max_rel_diff": worst,
+        "strong_scaling": ref["ms_per_step"] / lineN["ms_per_step"],
+        "strong_scaling_serial_reference": ref["serial_ms_per_step"] / lineN["ms_per_step"],
+        "compute_scaling": (ref.get("kernel_ms") or ref["serial_ms_per_step"]) / slowest,
+        "exposed_allreduce_ms_per_step": mg.get("exposed_allreduce_ms_per_step"),
+        "launch_skew_median_ms": (mg.get("launch_skew") or {}).get("median_ms"),
+        "single_call_ms": {"rccl": mg.get("single_call_ms"), "host_sum": mg.get("single_call_host_sum_ms")},
+        "rank_imbalance": max(mg["per_rank_kernel_ms"]) / min(mg["per_rank_kernel_ms"]),
+    }
+    if not lineN.get("rehearsal"):
+        assert lineN["ms_per_step"] >= 0.9 * slowest / max(1, cN.get("streams_per_gpu", 1)), \
+            "ms_per_step %.4f is below the slowest rank's kernel time %.4f: the timed region cannot have held K full steps" % (lineN["ms_per_step"], slowest)
+    # the verdict in words: where a shortfall against N x comes from
+    target = 7.0 / 8.0 * n
+    if report["strong_scaling"] >= target:
+        report["verdict"] = "scales: %.2fx on %d GPUs (>= %.2fx)" % (report["strong_scaling"], n, target)
+    elif report["compute_scaling"] < target:
+        report["verdict"] = "compute-bound shortfall: the slowest rank's kernel alone scales %.2fx (shard too small / rank imbalance %.3f)" % (report["compute_scaling"], report["rank_imbalance"])
+    else:
+        report["verdict"] = "collective exposed: kernels scale %.2fx but the step %.2fx; exposed all-reduce %.4f ms per step, launch skew %.4f ms" % (
+            report["compute_scaling"], report["strong_scaling"], report["exposed_allreduce_ms_per_step"] or float("nan"), report["launch_skew_median_ms"] or float("nan"))
+    return report

@@ -125,6 +125,17 @@ int ora_vega_pathwise_f64(const ora_model* m, double sigma, const double* drift,
                           int64_t n_paths, uint64_t seed, uint64_t path_offset,
                           double S1, double S2, double K, double out[1], int n_threads);
 
+/* The same loop with the scale of the sum beside it: out[0] = sum(term1 - term2), out[1] = sum |term1|, out[2] = sum |term2|
+ * (3_sens:72-80; the two absolute sums are not in the reference: they scale the tests' error bounds for a sum of signed terms). */
+int ora_vega_pathwise_terms_f32(const ora_model* m, double sigma, const float* drift,
+                                const float* sigma_drift, const float* P, const float* f,
+                                int64_t n_paths, uint64_t seed, uint64_t path_offset,
+                                double S1, double S2, double K, double out[3], int n_threads);
+int ora_vega_pathwise_terms_f64(const ora_model* m, double sigma, const double* drift,
+                                const double* sigma_drift, const float* P, const float* f,
+                                int64_t n_paths, uint64_t seed, uint64_t path_offset,
+                                double S1, double S2, double K, double out[3], int n_threads);
+
 /* simulate_paths_show, include/market_data.cuh:136-160.  out[n][n_steps+1], row-major. */
 int ora_sample_paths_f32(const ora_model* m, double sigma, const float* drift,
                          int n, uint64_t seed, uint64_t path_offset, float* out);

@@ -225,6 +225,24 @@ class Oracle:
             raise RuntimeError("ora_vega_pathwise rc=%d" % rc)
         return float(out[0])
 
+    def vega_pathwise_terms(self, P, f, n_paths, seed, path_offset=0, S1=5.0, S2=10.0, K=None,
+                            sigma=None, n_threads=None):
+        """(sum(term1 - term2), sum |term1|, sum |term2|): the Vega sum and the scale of its signed terms."""
+        K = float(np.exp(np.float32(-0.1))) if K is None else K
+        sigma = sigma or self.m.sigma
+        drift, sdrift = self.tables(sigma)
+        P = np.ascontiguousarray(P, np.float32)
+        f = np.ascontiguousarray(f, np.float32)
+        out = np.zeros(3, np.float64)
+        rc = self._fn("ora_vega_pathwise_terms")(
+            C.byref(self.m), C.c_double(sigma), self._rp(drift), self._rp(sdrift), _fp(P), _fp(f),
+            C.c_int64(n_paths), C.c_uint64(seed), C.c_uint64(path_offset),
+            C.c_double(S1), C.c_double(S2), C.c_double(K), _dp(out),
+            C.c_int(n_threads or self.max_threads()))
+        if rc != 0:
+            raise RuntimeError("ora_vega_pathwise_terms rc=%d" % rc)
+        return float(out[0]), float(out[1]), float(out[2])
+
     def sample_paths(self, n, seed, path_offset=0, sigma=None):
         sigma = sigma or self.m.sigma
         drift = np.zeros(self.m.n_steps, np.float32)

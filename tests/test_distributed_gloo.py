@@ -143,3 +143,122 @@ def test_strong_scaling_per_call_all_reduce(every, expected, oracle_mod, hwmc_mo
         assert all(set(prods) <= {0, 1} and prods for _, _, prods in messages)   # the streams whose launches the message waits for
         for i, row in enumerate(rows):
             np.testing.assert_allclose(row, o.zbc_moments(P, f, 512, 1234 + 12345 * i), rtol=1e-13)
+
+
+def _selfcheck_worker(rank, world, port, wrong_seed_rank, q):
+    """Two ranks build what bench.py --gpus 2 puts into its line's self-check fields (hwmc.parallel.world_size_seen,
+    launch_skew, gather_floats) around an oracle-computed, gloo-reduced pricing call; rank 0 hands the line out."""
+    import time
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import hw_oracle
+    import hwmc
+    par = hwmc.parallel
+    n_total = par.pricing_workload(world, "strong", pairs_log2=6, total_log2=9)
+    off, cnt = par.shard(n_total, rank, world)
+    p = hwmc.default_params("head")
+    P, f = hwmc.analytic_curve(p)
+    o = hw_oracle.Oracle("head")
+    starts = []
+    for _ in range(3):                                     # three "timed regions": barrier, note the host clock, work
+        dist.barrier()
+        starts.append(time.time())
+        time.sleep(0.001 * rank)
+    seed = 1234 + (1 if rank == wrong_seed_rank else 0)    # a rank pricing another sample set must be caught
+    t0 = time.perf_counter()
+    sums = torch.from_numpy(o.zbc_moments(P, f, cnt, seed, path_offset=off, n_threads=1)).clone()
+    kernel_ms = (time.perf_counter() - t0) * 1e3
+    par.allreduce_sums(sums)
+    step_ms = (time.perf_counter() - t0) * 1e3
+    tmax = torch.tensor([step_ms], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    mg = {"world_size_seen": par.world_size_seen(), "launch_skew": par.launch_skew(starts),
+          "per_rank_kernel_ms": [r[0] for r in par.gather_floats([kernel_ms])],
+          "compute_only_ms_per_step": None, "exposed_allreduce_ms_per_step": 0.0, "single_call_ms": step_ms, "single_call_host_sum_ms": step_ms}
+    ms = float(tmax.item())
+    line = {"metric": "M paths/sec (ZBC option, 1000 steps)", "unit": "M paths/s", "dtype": "f32", "n_gpus": world, "scaling": "strong",
+            "ms_per_step": ms, "value": 2 * n_total / ms / 1000.0, "sums_step0": sums.tolist(), "multi_gpu": mg, "rehearsal": "cpu oracle over gloo",
+            "config": {"grid_steps": 1000, "steps_executed": 500, "stepper": "superposed", "theta_profile": "head", "pairs_per_step": n_total,
+                       "effective_paths": 2 * n_total, "streams_per_gpu": 1}}
+    if rank == 0:
+        q.put(line)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _two_rank_line(wrong_seed_rank=-1):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_selfcheck_worker, args=(r, world, port, wrong_seed_rank, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    line = q.get(timeout=180)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    return line
+
+
+def test_an_n_gpu_line_checks_itself_against_the_n1_line(oracle_mod, hwmc_mod):
+    """no N > 1 run has ever executed on hardware, so the first one must be self-checking.
+    hwmc.parallel.check_scaling_lines takes the N = 1 line (with strong_scaling_reference.sums_step0) and an N-GPU line and
+    asserts: every rank took part (torch's world size == an all-reduce of ones == n_gpus), the SAME sample set was priced
+    (sums of the first timed step equal to 1e-13), value == paths / time; its report carries the fields that decide between
+    '>= 7x' and 'collective exposed'.  Here the two ranks' line is built over gloo with the CPU oracle as the compute."""
+    import copy
+    import time
+    par = hwmc_mod.parallel
+    p = hwmc_mod.default_params("head")
+    P, f = hwmc_mod.analytic_curve(p)
+    o = oracle_mod.Oracle("head")
+    t0 = time.perf_counter()
+    whole = o.zbc_moments(P, f, 512, 1234, n_threads=1)
+    ms1 = (time.perf_counter() - t0) * 1e3
+    line1 = {"metric": "M paths/sec (ZBC option, 1000 steps)", "unit": "M paths/s", "dtype": "f32", "n_gpus": 1, "scaling": "strong",
+             "config": {"grid_steps": 1000, "steps_executed": 500, "stepper": "superposed", "theta_profile": "head", "pairs_per_step": 64},
+             "strong_scaling_reference": {"pairs_per_step": 512, "n_gpus": 1, "ms_per_step": ms1, "serial_ms_per_step": ms1, "kernel_ms": ms1,
+                                          "sums_step0": [float(x) for x in whole]}}
+    lineN = _two_rank_line()
+    rep = par.check_scaling_lines(line1, lineN)
+    assert rep["n_gpus"] == 2 and rep["sums_step0_max_rel_diff"] <= 1e-13
+    assert lineN["multi_gpu"]["world_size_seen"] == {"dist": 2, "allreduce_of_ones": 2}
+    sk = lineN["multi_gpu"]["launch_skew"]
+    assert sk["regions"] == 3 and 0.0 <= sk["median_ms"] <= sk["max_ms"] < 1000.0
+    assert len(lineN["multi_gpu"]["per_rank_kernel_ms"]) == 2 and rep["strong_scaling"] > 0 and "verdict" in rep
+    # a rank that priced another sample set (wrong seed on rank 1) is caught by the sums, nothing else would notice
+    with pytest.raises(AssertionError, match="did not price the N = 1 sample set"):
+        par.check_scaling_lines(line1, _two_rank_line(wrong_seed_rank=1))
+    # a rank missing from the collective / a launcher that started fewer processes
+    bad = copy.deepcopy(lineN)
+    bad["multi_gpu"]["world_size_seen"]["allreduce_of_ones"] = 1
+    with pytest.raises(AssertionError, match="ranks seen"):
+        par.check_scaling_lines(line1, bad)
+    bad = copy.deepcopy(lineN)
+    bad["config"]["pairs_per_step"] = 256
+    with pytest.raises(AssertionError, match="pairs per call"):
+        par.check_scaling_lines(line1, bad)
+    bad = copy.deepcopy(lineN)
+    bad["value"] *= 1.5
+    with pytest.raises(AssertionError, match="effective_paths / ms_per_step"):
+        par.check_scaling_lines(line1, bad)
+    with pytest.raises(AssertionError, match="no strong_scaling_reference"):
+        par.check_scaling_lines({k: v for k, v in line1.items() if k != "strong_scaling_reference"}, lineN)
+    # the three verdicts, on synthetic timings of an 8-GPU line: scales / compute-bound shortfall / collective exposed
+    def synth(step_ms, kernel_ms, exposed):
+        d = copy.deepcopy(lineN)
+        d["n_gpus"] = 8
+        d["rehearsal"] = "synthetic"
+        d["ms_per_step"] = step_ms
+        d["value"] = d["config"]["effective_paths"] / step_ms / 1000.0
+        d["multi_gpu"].update(world_size_seen={"dist": 8, "allreduce_of_ones": 8}, per_rank_kernel_ms=[kernel_ms] * 8,
+                              exposed_allreduce_ms_per_step=exposed, launch_skew={"median_ms": 0.004, "max_ms": 0.01, "regions": 7})
+        return d
+    ref = copy.deepcopy(line1)
+    ref["strong_scaling_reference"].update(ms_per_step=2.74, serial_ms_per_step=2.77, kernel_ms=2.77)
+    assert par.check_scaling_lines(ref, synth(0.36, 0.355, 0.004))["verdict"].startswith("scales: 7.61x on 8 GPUs")
+    assert par.check_scaling_lines(ref, synth(0.45, 0.44, 0.005))["verdict"].startswith("compute-bound shortfall")
+    assert par.check_scaling_lines(ref, synth(0.45, 0.355, 0.09))["verdict"].startswith("collective exposed")
