@@ -693,14 +693,34 @@ def test_full_size_properties_of_the_multi_gpu_shares(setup, hwmc_mod):
 
 
 def test_random_models_against_the_double_oracle(hwmc_mod, oracle_mod):
-    """The reference hard-codes one model (common.cuh:16-39); the C ABI takes it as parameters.  24 random models -- mean
+    """The reference hard-codes one model (common.cuh:16-39); the C ABI takes it as parameters.  40 random models -- mean
     reversion, volatility, r0, both theta pieces and the break, grid lengths that are and are not multiples of four, maturity
-    counts, exercise / maturity / strike -- through all three kernels, the FD scenarios, the batched runs and (float) the reference stepper, DOUBLE engine against the double oracle at 2e-6
-    (same normals, so this is sharp: a wrong index, table entry or hoisted constant shows as 1e-3 or worse), and the float
-    engine against the same double sums at 5e-5 (float steppers drift ~1e-5 from double away from a = 1, see the
-    weak-mean-reversion test)."""
+    counts, exercise / maturity / strike -- through all three kernels, the FD scenarios, the batched runs and (float) the reference stepper:
+
+      * DOUBLE engine against the double oracle at 2e-6 (same normals, so this is sharp: a wrong index, table entry or hoisted
+        constant shows as 1e-3 or worse);
+      * float engine against the same double sums at 5e-5;
+      * float engine, BOTH steppers, against the FLOAT oracle -- the reference's own per-step float32 arithmetic -- at the
+        north-star tolerance REL_F32 = 1e-5 wherever float32 arithmetic determines the sums that well.  It does not everywhere:
+        at low volatility the payoff max(P - K, 0) is a difference of nearly equal numbers, and the float oracle ITSELF sits up
+        to 3e-5 from the double oracle (c below; measured envelope, tools/labs/parity_envelope.py, profiles/r04_parity_envelope.txt:
+        c > 1e-5 on 5 of the 40 models, all with sigma < 0.07).  So every model is held to max(1e-5, 2 c) -- the engine is as close
+        to the reference's float arithmetic as that arithmetic is to the exact sums -- and at least 32 of the 40 must meet the plain
+        1e-5 with both steppers (measured: 35; superposed stepper alone 36; worst 2.7e-5 / 3.3e-5 on the model with c = 3.0e-5);
+        the curve meets the plain 1e-5 on all 40 (measured worst 3.4e-7);
+      * pathwise Vega: a sum of terms of both signs, so its error is held against the scale of the terms,
+        tol x (sum |term1| + sum |term2|) (3_sens:72-80; the oracle reports the two absolute sums): 2e-6 for the double engine
+        (measured worst 5.3e-7), 1e-5 for the float engine against either oracle (measured worst 2.7e-6)."""
     rng = np.random.default_rng(20250607)
-    for case in range(24):
+    rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.abs(np.asarray(b))))
+    plain, worst = 0, {"superposed": (0.0, None), "reference": (0.0, None), "curve": (0.0, None), "vega_f32": (0.0, None), "vega_f64": (0.0, None)}
+
+    def note(key, val, case):
+        if val > worst[key][0]:
+            worst[key] = (val, case)
+
+    n_models = 40
+    for case in range(n_models):
         n_mat = int(rng.choice([11, 21, 51, 101]))
         per = int(rng.choice([2, 3, 4, 5, 8, 10, 12]))                     # steps per maturity: odd ones take the generic curve kernel
         n_steps = per * (n_mat - 1)
@@ -720,14 +740,17 @@ def test_random_models_against_the_double_oracle(hwmc_mod, oracle_mod):
                 engines[prec] = hwmc_mod.HullWhiteEngine(p, device=0)
             P, f = hwmc_mod.analytic_curve(engines["f64"].params)
             o = oracle_mod.Oracle("head", n_steps=n_steps, n_mat=n_mat, precision="f64")
+            o32 = oracle_mod.Oracle("head", n_steps=n_steps, n_mat=n_mat, precision="f32")
             for k, v in fields.items():
                 setattr(o.m, k, v)
+                setattr(o32.m, k, v)
             fwd = float(np.interp(S2, np.arange(n_mat) * spacing, P) / np.interp(S1, np.arange(n_mat) * spacing, P))
             K = fwd * float(rng.uniform(0.97, 1.03))                        # around the money
             n, seed = int(rng.integers(500, 6000)), int(rng.integers(1, 1 << 40))
             want = o.zbc_moments(P, f, n, seed, S1=S1, S2=S2, K=K)
             wantc = o.zcb_curve(n, seed)
-            wantv = o.vega_pathwise(P, f, n, seed, S1=S1, S2=S2, K=K)
+            wantv, abs1, abs2 = o.vega_pathwise_terms(P, f, n, seed, S1=S1, S2=S2, K=K)
+            vscale = abs1 + abs2                                            # the scale of the Vega sum's signed terms
             for prec, tol in (("f64", REL_F64), ("f32", 5e-5)):
                 e = engines[prec]
                 e.load_market_data(P, f)
@@ -735,7 +758,9 @@ def test_random_models_against_the_double_oracle(hwmc_mod, oracle_mod):
                 np.testing.assert_allclose(e.simulate_ZBC_control_variate(n, seed, S1=S1, S2=S2, K=K), want, rtol=tol, atol=tol * abs(want[1]) * 1e-3, err_msg=str(tag))
                 np.testing.assert_allclose(e.simulate_zcb(n, seed), wantc, rtol=tol, err_msg=str(tag))
                 got = e.simulate_sensitivity(n, seed, S1=S1, S2=S2, K=K)
-                assert abs(got - wantv) <= 20 * tol * max(abs(wantv), 1e-3 * n), (tag, got, wantv)   # a sum of terms of both signs
+                vtol = REL_F64 if prec == "f64" else REL_F32
+                assert abs(got - wantv) <= vtol * vscale, (tag, got, wantv, vscale, abs(got - wantv) / vscale)
+                note("vega_" + prec, abs(got - wantv) / vscale, case)
                 # the finite-difference scenarios (sigma -+ eps with the shifted drift table, 3_sens:374-446) from ONE pass
                 s0, eps = fields["sigma"], 1e-3
                 sc = e.simulate_ZBC_scenarios(n, seed, [s0 - eps, s0 + eps], [hwmc_mod.HW_DRIFT_SHIFTED] * 2, S1=S1, S2=S2, K=K)
@@ -745,11 +770,30 @@ def test_random_models_against_the_double_oracle(hwmc_mod, oracle_mod):
                 np.testing.assert_allclose(e.simulate_ZBC_runs(n, seed, n_runs=3, seed_stride=977, S1=S1, S2=S2, K=K)[2],
                                            o.zbc_moments(P, f, n, seed + 2 * 977, S1=S1, S2=S2, K=K), rtol=tol, atol=tol * abs(want[1]) * 1e-3, err_msg=str(tag))
             # the reference stepper (float only): evolve_hull_white_step verbatim with the drift table on the device
-            ref = engines["f32"].simulate_ZBC_control_variate(n, seed, S1=S1, S2=S2, K=K, stepper=hwmc_mod.HW_STEPPER_REFERENCE)
+            e32 = engines["f32"]
+            sup = e32.simulate_ZBC_control_variate(n, seed, S1=S1, S2=S2, K=K)
+            ref = e32.simulate_ZBC_control_variate(n, seed, S1=S1, S2=S2, K=K, stepper=hwmc_mod.HW_STEPPER_REFERENCE)
             np.testing.assert_allclose(ref, want, rtol=5e-5, atol=5e-8 * abs(want[1]), err_msg=str((case, "reference stepper", fields)))
+            # ---- the float engine against the FLOAT oracle (the reference's arithmetic) at the north-star tolerance
+            want32 = o32.zbc_moments(P, f, n, seed, S1=S1, S2=S2, K=K)
+            c = rel(want32, want)                                           # how well float32 arithmetic determines these sums at all
+            d_sup, d_ref = rel(sup, want32), rel(ref, want32)
+            bound = max(REL_F32, 2.0 * c)
+            assert d_sup <= bound and d_ref <= bound, (case, fields, "superposed %.2e reference %.2e vs float oracle; float oracle vs double oracle %.2e" % (d_sup, d_ref, c))
+            plain += d_sup <= REL_F32 and d_ref <= REL_F32
+            note("superposed", d_sup, case)
+            note("reference", d_ref, case)
+            d_curve = rel(e32.simulate_zcb(n, seed)[1:], o32.zcb_curve(n, seed)[1:])
+            assert d_curve <= REL_F32, (case, fields, d_curve)
+            note("curve", d_curve, case)
+            v32, a1, a2 = o32.vega_pathwise_terms(P, f, n, seed, S1=S1, S2=S2, K=K)
+            got32 = e32.simulate_sensitivity(n, seed, S1=S1, S2=S2, K=K)
+            assert abs(got32 - v32) <= REL_F32 * (a1 + a2), (case, fields, got32, v32, a1 + a2)
         finally:
             for e in engines.values():
                 e.close()
+    assert plain >= 32, "only %d of %d models meet the plain 1e-5 against the float oracle with both steppers; worst cases %r" % (plain, n_models, worst)
+    print("parity envelope over %d random models: %d at the plain 1e-5 (both steppers); worst (value, case): %r" % (n_models, plain, worst))
 
 
 def test_configs_3_and_4_whole_on_one_gpu(setup, hwmc_mod):
@@ -854,8 +898,8 @@ def test_random_parameter_sweep_against_the_double_oracle(hwmc_mod, oracle_mod):
             assert np.all(np.isfinite(got)), ctx
             np.testing.assert_allclose(got, o.zbc_moments(P, f, n, seed, S1=S1, S2=S2, K=K), rtol=tol, err_msg=ctx)
             v = e.simulate_sensitivity(n, seed + 1, S1=S1, S2=S2, K=K)
-            vo = o.vega_pathwise(P, f, n, seed + 1, S1=S1, S2=S2, K=K)
-            assert abs(v - vo) <= 20 * tol * max(abs(vo), n * 1e-3), ctx          # a sum of signed terms: absolute floor
+            vo, abs1, abs2 = o.vega_pathwise_terms(P, f, n, seed + 1, S1=S1, S2=S2, K=K)
+            assert abs(v - vo) <= tol * (abs1 + abs2), (ctx, abs(v - vo) / (abs1 + abs2))   # a sum of signed terms: against the scale of the terms
             np.testing.assert_allclose(e.simulate_zcb(n, seed + 2), o.zcb_curve(n, seed + 2), rtol=tol, err_msg=ctx)
             e.close()
 

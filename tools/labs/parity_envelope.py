@@ -18,7 +18,7 @@ rng = np.random.default_rng(20250607)
 rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.maximum(np.abs(np.asarray(b)), 1e-300)))
 print("case  a     sigma  steps guard | sup-o32  ref-o32  sup-o64  o32-o64 | curve: sup-o32 o32-o64 | vega/scale: sup-o32 sup-o64 o32-o64 d64-o64")
 worst = np.zeros(10)
-for case in range(24):
+for case in range(int(sys.argv[1]) if len(sys.argv) > 1 else 24):
     n_mat = int(rng.choice([11, 21, 51, 101]))
     per = int(rng.choice([2, 3, 4, 5, 8, 10, 12]))
     n_steps = per * (n_mat - 1)
