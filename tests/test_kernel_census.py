@@ -231,7 +231,80 @@ def test_the_issue_bound_probe_times_the_production_loop():
     assert n_valu == 60
     # the committed measurement was taken for this census
     import json
-    prof = json.load(open(os.path.join(ROOT, "profiles", "r03_mix_bound.json")))
+    prof = json.load(open(os.path.join(ROOT, "profiles", "r04_mix_bound.json")))
     assert prof["census_per_block"] == {"full": 32, "half": 20, "quarter": 8}
     assert 144.0 <= prof["exclusive_classes_measured"] < prof["bound_cycles_per_block"] <= prof["nominal_serial_model"] == 208
     assert abs(prof["real_loop_cycles_per_block"]["one_pair_per_thread"] - prof["bound_cycles_per_block"]) < 1.0
+
+
+def test_the_other_two_production_loops_have_twins_of_their_own():
+    """the double ZBC loop and the curve loop are priced against THEIR OWN measured issue bound, not the
+    float ZBC loop's.  Pinned here, without a GPU, from the generated twin bodies (the staleness of the whole file is the test
+    above): the double loop's census (the float loop's 16 wide multiplies, 8 transcendentals and bitwise rounds + 3 v_cvt_f64_f32,
+    2 v_fma_f64 and 1 v_add_f64 per block), and the curve twins' structure -- one trip = one period of sixteen maturities, with
+    exactly the trips the event logic of zcb_curve_blocked_kernel takes in it (1000-step grid: 24 event-free trips, 8 with a
+    maturity after the first half block, 8 after the second; 4000-step grid: 144 + 16), every butterfly depth 0..4 as often as
+    trailing-ones(m & 15) says, ONE flush; two v_exp_f32 per event and pair; no LDS access, compare or branch of the production
+    loop left in a twin (they can only lower a bound)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_mix_bound as g
+    committed = open(os.path.join(ROOT, "tools", "mix_bound_body.inc")).read()
+
+    def body(name):
+        txt = committed.split("#define MIX_BODY_%s " % name)[1].split("#define MIX_CLOBBERS_%s" % name)[0]
+        return re.findall(r'"([^"]*?)\\n', txt)
+    f64 = body("F64_1")
+    ops = [l.split()[0] for l in f64]
+    count = lambda pre: sum(o.startswith(pre) for o in ops)
+    assert count("v_mad_u64_u32") == 16 and count("v_cvt_f32_u32") == 4 and count("v_cvt_f64_f32") == 3
+    assert count("v_fma_f64") + count("v_fmac_f64") == 2 and count("v_add_f64") == 1
+    assert sum(count(t) for t in ("v_log_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32")) == 8 and count("v_exp") == 0
+    assert g.census_of(f64) == {"full": 30, "half": 26, "quarter": 8}
+    assert [l for l in body("REALF64_1") if l.startswith("v_")] != [l for l in f64 if l.startswith("v_")]      # (REAL: real registers)
+    assert [l.split()[0] for l in body("REALF64_1") if l.startswith("v_")] == [o for o in ops if o.startswith("v_")]
+    # the event logic, restated by gen_mix_bound.curve_period and checked here against first principles
+    for n_steps, n_events_1, n_events_2, n_trips in ((1000, 8, 8, 40), (4000, 0, 16, 160)):
+        units, trips = g.curve_period(n_steps)
+        kinds = [k for u in units for k, _ in u]
+        assert trips == n_trips == len(kinds) == 16 * (n_steps // 100) // 4
+        assert sum(k[0] == 1 for k in kinds) == n_events_1 and sum(k[0] == 2 for k in kinds) == n_events_2
+        levels = sorted(k[1] for k in kinds if k[0])
+        assert levels == sorted(min(4, (~m & (m + 1)).bit_length() - 1) for m in range(1, 17))   # trailing ones of m & 15, capped at 4
+        assert sum(k[2] for k in kinds) == 1
+    for name, P, n_trips, n_events in (("CURVE1", 1, 40, 16), ("CURVE4", 4, 160, 16), ("CURVE4_F64", 4, 160, 16)):
+        lines = body(name)
+        assert re.search(r"#define MIX_BLOCKS_%s %d\n" % (name, n_trips * P), committed)
+        assert not [l for l in lines if l.startswith(("ds_", "s_waitcnt", "s_bitcmp"))]
+        branches = [l for l in lines if l.startswith(("s_cbranch", "s_cmp", "s_branch"))]
+        assert all(re.match(r"^(s_cmp_lg_u32 s7[23], 0|s_cbranch_scc1 \d+b)$", l) for l in branches), branches[:3]   # the twin's own counted loops only
+        # executed instruction counts over one trip of the twin: unroll its counted loops
+        def executed(lines):
+            stack, out = [], {}
+            counts, i = {}, 0
+            mult = 1
+            frames = []
+            for l in lines:
+                m = re.match(r"^s_mov_b32 (s7[23]), (\d+)$", l)
+                if m:
+                    frames.append(int(m.group(2)))
+                    mult *= frames[-1]
+                    continue
+                if re.match(r"^s_cbranch_scc1 \d+b$", l):
+                    mult //= frames.pop()
+                    continue
+                op = l.split()[0]
+                counts[op] = counts.get(op, 0) + mult
+            return counts
+        ex = executed(lines)
+        assert ex["v_mad_u64_u32"] == 16 * P * n_trips
+        assert ex["v_exp_f32_e32"] + ex["v_exp_f32_e64"] == 2 * P * n_events
+        assert ex["v_add_f32_dpp"] == sum(min(4, (~m & (m + 1)).bit_length() - 1) for m in range(1, 17))   # 15 butterfly merges per 16 maturities
+        assert ex.get("v_cvt_f64_f32_e32", 0) >= 1                                                     # the flush's conversion (+ the double state's)
+    # the committed measurement: every family has a bound, the straight-line loops reproduce their own rate in the harness,
+    # and the curve loops cost more than the ZBC loop they contain
+    import json
+    loops = json.load(open(os.path.join(ROOT, "profiles", "r04_mix_bound.json")))["loops"]
+    assert set(loops) >= {"zbc_f32", "zbc_f64", "curve_f32_p1", "curve_f32_p4", "curve_f64_p4"}
+    assert abs(loops["zbc_f64"]["real_loop_cycles_per_block"] - loops["zbc_f64"]["bound_cycles_per_block"]) < 1.0
+    assert loops["zbc_f32"]["bound_cycles_per_block"] < loops["curve_f32_p4"]["bound_cycles_per_block"] < loops["curve_f32_p1"]["bound_cycles_per_block"]
+    assert loops["zbc_f32"]["bound_cycles_per_block"] < loops["zbc_f64"]["bound_cycles_per_block"] < loops["curve_f64_p4"]["bound_cycles_per_block"]
