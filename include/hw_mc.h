@@ -226,8 +226,11 @@ int  hw_pipe_zbc_moments(hw_pipe* pipe, const hw_zbc_request* reqs, int32_t n, d
  * only if ALL of them succeeded -- otherwise nobody enters it, every device drains, the call returns "device <id>:
  * <text>" of the failing rank through hw_last_error() and the communicator stays usable.  A failure after that point
  * (inside the collective or the synchronisation behind it) aborts every communicator (ncclCommAbort, which releases
- * ranks blocked in the collective): the call returns the error and every later call on this hw_comm is refused;
- * destroy it and create a new one.  HWMC_COMM_INJECT_FAIL=rank:phase[:count] (read by hw_comm_create*) makes rank
+ * ranks blocked in the collective): the call returns the error of the rank that failed FIRST (the culprit -- not of a
+ * lower-ranked victim whose own calls then failed because of the abort) and every later call on this hw_comm is refused;
+ * destroy it and create a new one.  [That abort path has run with ONE rank only (no multi-GPU box was available to the
+ * authoring rounds); its host protocol is checked with 2, 3 and 8 workers against a mock collective under ThreadSanitizer,
+ * tests/cpp/fleet_probe.cpp, but ncclCommAbort from a peer's worker thread has never executed with G > 1.]  HWMC_COMM_INJECT_FAIL=rank:phase[:count] (read by hw_comm_create*) makes rank
  * `rank` fail in phase 1 or 2 of its next `count` jobs: the rehearsal tests' switch, not for production. */
 typedef struct hw_comm hw_comm;
 int  hw_comm_create(int32_t n, hw_ctx* const* ctxs, hw_comm** out);

@@ -1623,10 +1623,11 @@ static bool comm_inject(hw_comm* cm, int g, int phase)
     return cm->inject_left.fetch_sub(1, std::memory_order_acq_rel) > 0;
 }
 
-// release every rank that may be blocked in a collective: called once, by the first worker that fails in phase 2
-static void comm_abort_all(hw_comm* cm)
+// release every rank that may be blocked in a collective: called once, by the first worker that fails in phase 2 (the culprit:
+// its rank and text are what the caller is told, whatever errors the abort then causes on the other ranks)
+static void comm_abort_all(hw_comm* cm, int culprit_rank, const std::string& text)
 {
-    if (!cm->fleet.mark_broken()) return;
+    if (!cm->fleet.mark_broken(culprit_rank, text)) return;
     int cur = 0;
     (void)hipGetDevice(&cur);
     for (size_t i = 0; i < cm->comm.size(); i++) {
@@ -1677,10 +1678,14 @@ static int comm_run(hw_comm* cm, int64_t n_units, int count_out, double* out, fl
             if (rc == HW_OK && g == 0) e = hipMemcpyAsync(out, c->d_out, count_out * sizeof(double), hipMemcpyDeviceToHost, c->stream);
             if (rc == HW_OK && e == hipSuccess) e = hipStreamSynchronize(c->stream);
         }
+        // a rank whose calls fail AFTER a peer has aborted the communicators is a victim, not a culprit: the abort makes a
+        // healthy rank's all-reduce kernel / stream synchronisation return errors too, and the culprit's text is the one to report
+        if ((rc != HW_OK || e != hipSuccess) && cm->fleet.broken()) return HW_OK;
         if (rc == HW_OK && e != hipSuccess) rc = fail(HW_E_HIP, "HIP error behind the collective: %s", hipGetErrorString(e));
         if (rc != HW_OK) {
             *text = g_err;
-            if (!cm->host_sum) comm_abort_all(cm);             // the other ranks may be blocked in the all-reduce: release them
+            if (!cm->host_sum) comm_abort_all(cm, g, g_err);    // the other ranks may be blocked in the all-reduce: release them
+                                                                // (HW_COMM_HOST_SUM has no collective: reported, the fleet goes on)
             return rc;
         }
         if (cm->fleet.broken()) return HW_OK;                   // released by a peer's abort: its error is the one reported
@@ -1688,8 +1693,12 @@ static int comm_run(hw_comm* cm, int64_t n_units, int count_out, double* out, fl
         return HW_OK;
     };
     int rc = comm_dispatch(cm, job);
-    if (rc == HW_OK && cm->fleet.broken())
-        rc = fail(HW_E_HIP, "a device failed inside the collective; the communicator was aborted");
+    if (cm->fleet.broken()) {                                   // whatever the lowest failing rank said: the culprit's rank and text
+        std::string why;
+        const int who = cm->fleet.culprit(&why);
+        rc = who >= 0 ? fail(HW_E_HIP, "device %d: %s (the communicator was aborted)", cm->ctx[who]->device, why.c_str())
+                      : fail(HW_E_HIP, "a device failed inside the collective; the communicator was aborted");
+    }
     if (rc == HW_OK && cm->host_sum)
         for (int k = 0; k < count_out; k++) {
             double t = 0.0;

@@ -12,7 +12,8 @@
 //     rc = <phase 1: everything that can fail on this device alone, no collective>
 //     if (!fleet.rendezvous(rc)) { <drain this device>; return rc; }   // somebody failed: NOBODY enters the collective
 //     <phase 2: the collective>                                       // every rank got through phase 1
-//     on a failure in phase 2:  if (fleet.mark_broken()) <abort the collective for ALL ranks>;  return error;
+//     on a failure in phase 2:  if (fleet.broken()) return 0;          // a victim of a peer's abort: the culprit reports
+//                               if (fleet.mark_broken(rank, text)) <abort the collective for ALL ranks>;  return error;
 // rendezvous() is a barrier over the G workers of the current job (every worker runs every job, so they all arrive).
 // A failure after the rendezvous cannot be undone rank by rank: the first worker to call mark_broken() gets `true` and must
 // release the ranks that may be blocked in the collective (ncclCommAbort); the fleet is then broken() for good.
@@ -102,7 +103,24 @@ public:
     }
 
     bool mark_broken() { return !broken_.exchange(true, std::memory_order_acq_rel); }   // true for the first caller only
+    // The same, remembering WHO broke the fleet: the first caller's rank and text are kept (culprit()), so that the error that
+    // reaches the user is the culprit's and not that of a lower-ranked victim whose own calls failed because of the abort.
+    bool mark_broken(int rank, const std::string& text)
+    {
+        std::lock_guard<std::mutex> lk(culprit_mu_);
+        if (broken_.load(std::memory_order_acquire)) return false;
+        culprit_rank_ = rank;
+        culprit_text_ = text;
+        broken_.store(true, std::memory_order_release);
+        return true;
+    }
     bool broken() const { return broken_.load(std::memory_order_acquire); }
+    int culprit(std::string* text)
+    {
+        std::lock_guard<std::mutex> lk(culprit_mu_);
+        if (text) *text = culprit_text_;
+        return culprit_rank_;
+    }
 
 private:
     static void cpu_relax()
@@ -149,6 +167,9 @@ private:
     std::atomic<uint64_t> generation_{0};
     std::atomic<int> pending_{0}, arrived_{0}, phase1_failed_{0};
     std::atomic<bool> broken_{false};
+    std::mutex culprit_mu_;
+    int culprit_rank_ = -1;
+    std::string culprit_text_;
     bool quit_ = false;
     const Job* job_ = nullptr;
     std::vector<int> rc_;

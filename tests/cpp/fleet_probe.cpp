@@ -104,11 +104,18 @@ int main(int argc, char** argv)
                 if (!fleet.rendezvous(0)) return -1;
                 if (g == victim) {                                                    // fails instead of entering: the others would wait for ever
                     *text = "phase 2 failed on rank " + std::to_string(g);
-                    if (fleet.mark_broken()) { aborts.fetch_add(1); coll.aborted.store(true, std::memory_order_release); }
+                    if (fleet.mark_broken(g, *text)) { aborts.fetch_add(1); coll.aborted.store(true, std::memory_order_release); }
                     return -4;
                 }
                 long r = 0;
-                if (!coll.all_reduce(1, &r)) return 0;                                // released by the victim's abort: its error is the one reported
+                if (!coll.all_reduce(1, &r)) {
+                    // released by the failing rank's abort.  The real collective then makes THIS rank's calls fail too (its
+                    // all-reduce kernel is aborted): the engine's rule is that a rank which finds the fleet broken reports
+                    // nothing of its own -- the culprit's rank and text are the ones the caller gets (fleet.culprit()).
+                    if (fleet.broken()) return 0;
+                    *text = "collateral error on rank " + std::to_string(g);
+                    return -5;
+                }
                 return 0;
             };
             const auto t0 = std::chrono::steady_clock::now();
@@ -118,6 +125,9 @@ int main(int argc, char** argv)
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) slow++;
             if (G == 1) { if (first != 0 || rc != -4) wrong++; }
             else if (first != victim || rc != -4 || aborts.load() != 1 || !fleet.broken()) wrong++;
+            std::string why;
+            if (G > 1 && (fleet.culprit(&why) != victim || why != "phase 2 failed on rank " + std::to_string(victim))) wrong++;
+            if (fleet.mark_broken(0, "late")) wrong++;                                // only the first failure is the culprit
             checks++;
         }
         // ---- part C: back-to-back tiny jobs (the spin path) and jobs after pauses (the sleep path)

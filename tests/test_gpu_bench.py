@@ -72,11 +72,30 @@ def test_bench_default_line_carries_the_side_measurements():
         assert d[key]["value"] > 0, key
     # the three rates the reference publishes (README.md:161-163), each in its own metric: Q2b = value, Q1, Q3
     assert d["q3_vega_gpu"]["paths"] == 1 << 20 and d["q3_vega_gpu"]["value"] > 509.0 and d["q3_vega_gpu"]["vs_v100_509"] > 1.0
-    # the VALU bound is MEASURED (tools/mix_bound.hip, live or the committed profile) and the launch cannot beat it
+    # the VALU reference rate is MEASURED (tools/mix_bound.hip, live or the committed profile): the dependency-free rate of the
+    # production ordering -- the fastest ordering tried, not a proven floor (that one is exclusive_classes_floor) -- and both it and
+    # the launch time are live measurements, so the comparison carries a 3 % tolerance instead of a strict inequality
     v = d["valu"]
     assert v["bound_cycles_per_block"] and 185.0 < v["bound_cycles_per_block"] < 200.0, v
-    assert 0.5 < v["frac"] <= 1.0 and 0.5 < v["frac_timed_region"] <= 1.0, v
-    assert v["exclusive_classes_floor"]["nominal_4_4_8"] == 144 and v["achieved_cycles_per_block_isolated_launch"] > v["bound_cycles_per_block"]
+    assert 0.5 < v["frac"] <= 1.03 and 0.5 < v["frac_timed_region"] <= 1.03, v
+    assert v["exclusive_classes_floor"]["nominal_4_4_8"] == 144 and v["achieved_cycles_per_block_isolated_launch"] > 0.97 * v["bound_cycles_per_block"]
+    assert v["achieved_cycles_per_block_isolated_launch"] > v["exclusive_classes_floor"]["nominal_4_4_8"]        # the provable floor
+    # BASELINE configs[2]'s finite-difference half, the 2^20..2^26 size table, the synchronous-call rate and configs[4] on one GPU
+    fd = d["q3_fd_vega_gpu"]
+    assert fd["scenarios"] == 3 and fd["value"] > 1064.0 and 0.15 < fd["vega_fd"] < 0.35 and 0.5 < fd["valu"]["frac"] <= 1.03
+    rows = d["size_table"]["rows"]
+    assert [r["pairs_log2"] for r in rows] == [20, 22, 24, 26] and all(r["value"] > 1064.0 and 0.5 < r["valu_frac"] <= 1.03 for r in rows)
+    assert rows[-1]["value"] > rows[0]["value"]                          # larger batches amortise the launch's fixed costs
+    sc = d["sync_call"]
+    assert sc["calls"] == 20 and sc["ms_per_call"] >= d["roofline"]["kernel_ms_min"] and sc["value"] > 1064.0
+    st = d["stress"]
+    for prec in ("f32", "f64"):
+        for k, loop in (("zbc", "zbc_" + prec), ("curve", "curve_%s_p4" % prec)):
+            x = st[prec][k]
+            assert x["value"] > 0 and x["hbm"]["frac"] < 1e-3 and x["valu"]["loop"] == loop and 0.5 < x["valu"]["frac"] <= 1.03, (prec, k, x)
+    assert 1.0 < st["f64_over_f32"]["zbc"] < 1.3 and 1.0 < st["f64_over_f32"]["curve"] < 1.3
+    assert d["q1_curve_gpu"]["valu"]["loop"] == "curve_f32_p1" and 0.5 < d["q1_curve_gpu"]["valu"]["frac"] <= 1.03
+    assert len(d["strong_scaling_reference"]["sums_step0"]) == 5 and d["strong_scaling_reference"]["kernel_ms"] > 0
     assert d["timed_region_s"] > 0
     assert d["long_region"]["steps"] == 60 and d["library_pipeline"]["api"] == "hw_pipe_zbc_moments" and d["library_pipeline"]["steps"] == 6
     assert d["strong_scaling_reference"]["pairs_per_step"] == 1 << 24 and d["config"]["pairs_per_step"] == 1 << 20
@@ -121,4 +140,20 @@ def test_bench_two_rank_strong_scaling_rehearsal(every, regions):
         whole = eng.simulate_ZBC_control_variate(1 << 18, 1234)        # the timed steps' first seed (2_option:229)
     np.testing.assert_allclose(d["sums_step0"], whole, rtol=1e-13)
     assert abs(d["price_mean"] - 0.0252555) < 5e-4
-    assert len(d["multi_gpu"]["per_rank_kernel_ms"]) == 2 and d["multi_gpu"]["single_call_ms"] > 0
+    mg = d["multi_gpu"]
+    assert len(mg["per_rank_kernel_ms"]) == 2 and mg["single_call_ms"] > 0
+    # the line checks itself: both ranks took part, the ranks' barrier release is timed, the same K steps
+    # were also run without the collective, and the host-sum form of one call sits beside the collective's
+    assert mg["world_size_seen"] == {"dist": 2, "allreduce_of_ones": 2}
+    assert mg["launch_skew"]["regions"] >= 1 and 0.0 <= mg["launch_skew"]["median_ms"] < 100.0
+    assert mg["compute_only_ms_per_step"] > 0 and mg["single_call_host_sum_ms"] > 0
+    assert mg["exposed_allreduce_ms_per_step"] == pytest.approx(d["ms_per_step"] - mg["compute_only_ms_per_step"], abs=1e-9)
+    if every == "1" and regions is None:
+        # ... and against the N = 1 line of the same build: the sample set must be the same to 1e-13
+        one = _bench("--steps", "3", "--regions", "2", "--total-log2", "18", env={"HWMC_BENCH_NO_STRESS": "1"})
+        rep = hwmc.parallel.check_scaling_lines(one, d)
+        assert rep["sums_step0_max_rel_diff"] <= 1e-13 and rep["n_gpus"] == 2 and "verdict" in rep
+        tampered = json.loads(json.dumps(d))
+        tampered["sums_step0"][0] *= 1.0 + 1e-9
+        with pytest.raises(AssertionError, match="did not price the N = 1 sample set"):
+            hwmc.parallel.check_scaling_lines(one, tampered)
