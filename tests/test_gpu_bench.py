@@ -147,7 +147,7 @@ def test_bench_two_rank_strong_scaling_rehearsal(every, regions):
     assert mg["world_size_seen"] == {"dist": 2, "allreduce_of_ones": 2}
     assert mg["launch_skew"]["regions"] >= 1 and 0.0 <= mg["launch_skew"]["median_ms"] < 100.0
     assert mg["compute_only_ms_per_step"] > 0 and mg["single_call_host_sum_ms"] > 0
-    assert mg["exposed_allreduce_ms_per_step"] == pytest.approx(d["ms_per_step"] - mg["compute_only_ms_per_step"], abs=1e-9)
+    assert mg["exposed_allreduce_ms_per_step"] == pytest.approx(d["ms_per_step"] - mg["compute_only_ms_per_step"], abs=2e-5)   # (ms_per_step is rounded to 5 places in the line)
     if every == "1" and regions is None:
         # ... and against the N = 1 line of the same build: the sample set must be the same to 1e-13
         one = _bench("--steps", "3", "--regions", "2", "--total-log2", "18", env={"HWMC_BENCH_NO_STRESS": "1"})
