@@ -971,6 +971,9 @@ def main():
             "serial": {"streams_per_gpu": 1, "ms_per_step": serial_ms, "value": (2 * shard_n / serial_ms) / 1000.0,
                        "vs_baseline": (2 * shard_n / serial_ms) / 1000.0 / V100_PUBLISHED_MPATHS,
                        "unit": "M paths/s per GPU", "on_a_caller_stream_ms_per_step": serial_caller_ms,
+                       "on_a_caller_stream_value": (2 * shard_n / serial_caller_ms) / 1000.0,
+                       "continuity": "rounds 1-2 reported `serial` on a caller's stream (= on_a_caller_stream_*); since round 3 `serial` is the "
+                                     "context's own stream",
                        "note": "same K launches strictly one after another on the context's own stream, no all-reduce; median of %d regions.  "
                                "on_a_caller_stream: the same through a stream of the caller's, where every call ends with one hipEventRecord "
                                "(the stream-lifetime rule of include/hw_mc.h)" % R_side},

@@ -166,6 +166,7 @@ struct GuardOps {
     const char* what = "";
     int record(hipStream_t s) { what = "hipEventRecord"; err = hipEventRecord(c->ev_tail, s); return err == hipSuccess ? 0 : 1; }
     int wait(hipStream_t s) { what = "hipStreamWaitEvent"; err = hipStreamWaitEvent(s, c->ev_tail, 0); return err == hipSuccess ? 0 : 1; }
+    int sync(hipStream_t s) { what = "hipStreamSynchronize"; err = hipStreamSynchronize(s); return err == hipSuccess ? 0 : 1; }
 };
 
 int guard_result(int r, const GuardOps& ops)
@@ -780,6 +781,7 @@ void hw_destroy(hw_ctx* c)
         const auto pend = c->guard.pending(&other);
         if (pend == hw::StreamGuard<hipStream_t>::Pending::TailEvent) (void)hipEventSynchronize(c->ev_tail);
         else if (pend == hw::StreamGuard<hipStream_t>::Pending::OwnedStream) (void)hipStreamSynchronize(other);
+        else if (pend == hw::StreamGuard<hipStream_t>::Pending::DeviceSync) (void)hipDeviceSynchronize();
     }
     free_retired(c);
     for (hw_ctx::Stage& sl : c->stage) {

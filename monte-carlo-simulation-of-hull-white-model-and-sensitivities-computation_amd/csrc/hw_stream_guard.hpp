@@ -15,7 +15,12 @@
 //
 // Ops must provide   int record(Stream s)        record the tail event on s (everything enqueued on s so far)
 //                    int wait(Stream s)          make s wait for the tail event as last recorded
+//                    int sync(Stream s)          block the host until everything enqueued on s has completed
 // returning 0 on success; any other value is passed through to the caller of enter()/leave().
+//
+// A record that FAILS on a caller's stream (leave()) must not leave the guard naming a stream it could never seal again
+// (every later call on another stream would be refused, and a destructor would free the workspaces under work still in
+// flight): the stream is drained on the host instead, while the handle is still valid, and the guard forgets it.
 #ifndef HW_STREAM_GUARD_HPP
 #define HW_STREAM_GUARD_HPP
 
@@ -36,14 +41,22 @@ public:
     int enter(Ops& ops, Stream st)
     {
         if (have_tail_ && !(tail_ == st)) {
+            bool drained = false;
             if (!recorded_) {
                 if (!owned(tail_)) return kGuardInternalError;
                 const int r = ops.record(tail_);             // an owned stream: alive by construction
-                if (r) return r;
-                recorded_ = true;
+                if (r) {                                     // the record failed: drain the owned stream on the host instead
+                    const int sy = ops.sync(tail_);
+                    if (sy) return sy;
+                    drained = true;
+                } else {
+                    recorded_ = true;
+                }
             }
-            const int w = ops.wait(st);
-            if (w) return w;
+            if (!drained) {
+                const int w = ops.wait(st);
+                if (w) return w;
+            }
         }
         recorded_ = false;                                   // new work is about to follow on st: the event no longer covers it
         tail_ = st;
@@ -57,24 +70,31 @@ public:
     {
         if (!have_tail_ || !(tail_ == st) || recorded_ || owned(st)) return 0;
         const int r = ops.record(st);                        // a caller's stream: NOW, while it is certainly alive
-        if (r) return r;
+        if (r) {
+            const int sy = ops.sync(st);                     // fall back: drain it on the host while the handle is valid ...
+            if (sy) { poisoned_ = true; return sy; }         // (nothing more can be done for this stream: destroy must sync the device)
+            have_tail_ = false;                              // ... and forget it: nothing of this context is in flight there any more
+            recorded_ = false;
+            return 0;
+        }
         recorded_ = true;
         return 0;
     }
 
     // what a destructor / host synchronisation has to wait for besides the context's own stream
-    enum class Pending { Nothing, TailEvent, OwnedStream };
+    enum class Pending { Nothing, TailEvent, OwnedStream, DeviceSync };
     Pending pending(Stream* which) const
     {
+        if (poisoned_) return Pending::DeviceSync;           // a caller's stream could be neither sealed nor drained
         if (!have_tail_ || (have_own_ && tail_ == own_)) return Pending::Nothing;
         if (recorded_) return Pending::TailEvent;
         if (owned(tail_)) { *which = tail_; return Pending::OwnedStream; }
-        return Pending::Nothing;                             // unreachable (see kGuardInternalError)
+        return Pending::DeviceSync;                          // an unsealed caller stream (cannot happen if every enter() has its leave()): be conservative
     }
 
 private:
     Stream own_{}, tail_{};
-    bool have_own_ = false, all_owned_ = false, have_tail_ = false, recorded_ = false;
+    bool have_own_ = false, all_owned_ = false, have_tail_ = false, recorded_ = false, poisoned_ = false;
 };
 
 }  // namespace hw

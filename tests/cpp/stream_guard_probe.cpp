@@ -9,6 +9,8 @@
 //             (checked against the latest 64: older ones precede those on whatever stream they ran);
 //   LIFETIME  no record() / wait() ever names a stream that is not alive;
 // and that round 2's lazy scheme (record on the remembered handle at the switch) violates LIFETIME on the same schedule.
+// Mode 2 repeats mode 0 with record() FAILING on one call in fifty: the guard must drain that stream on the host (sync),
+// forget it, and go on -- no later call refused, ORDER intact, nothing pending on a stream it can no longer name.
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -36,8 +38,28 @@ struct Mock {
     struct S { bool alive = false; Frontier frontier; };
     std::vector<S> streams;
     Frontier event;                            // what the tail event captured at its last record
-    long dead_stream_uses = 0, records = 0, waits = 0;
-    int record(int s) { records++; if (!streams[s].alive) { dead_stream_uses++; return 0; } event = streams[s].frontier; return 0; }
+    long dead_stream_uses = 0, records = 0, waits = 0, syncs = 0, failed_records = 0;
+    int fail_one_in = 0;                       // > 0: record() fails on one call in that many
+    std::mt19937 frng{777};
+    int record(int s)
+    {
+        records++;
+        if (!streams[s].alive) { dead_stream_uses++; return 0; }
+        if (fail_one_in > 0 && (int)(frng() % (unsigned)fail_one_in) == 0) { failed_records++; return 7; }
+        event = streams[s].frontier;
+        return 0;
+    }
+    // host synchronisation with s: everything enqueued on s so far has COMPLETED, so whatever is enqueued anywhere from now on runs after it
+    int sync(int s)
+    {
+        syncs++;
+        if (!streams[s].alive) { dead_stream_uses++; return 0; }
+        const Frontier done = streams[s].frontier;
+        for (auto& t : streams) if (t.alive) t.frontier.merge(done);
+        completed.merge(done);
+        return 0;
+    }
+    Frontier completed;                        // work known to have completed (a stream created later starts behind it)
     int wait(int s) { waits++; if (!streams[s].alive) { dead_stream_uses++; return 0; } streams[s].frontier.merge(event); return 0; }
 };
 
@@ -51,7 +73,7 @@ int main()
 {
     std::mt19937 rng(12345);
     long order_violations = 0, lazy_dead = 0, calls = 0, foreign_calls = 0, switches = 0;
-    for (int mode = 0; mode < 2; mode++) {               // 0: a plain context (own stream + callers' streams); 1: a pipe's context
+    for (int mode = 0; mode < 3; mode++) {               // 0: a plain context (own stream + callers' streams); 1: a pipe's context; 2: mode 0 with failing records
         Mock m, lazy_m;
         hw::StreamGuard<int> g;
         LazyGuard lazy;
@@ -60,18 +82,19 @@ int main()
         for (auto& s : m.streams) s.alive = true;
         g.set_own_stream(own);
         if (mode == 1) g.set_all_streams_owned(true);
+        if (mode == 2) m.fail_one_in = 50;
         lazy_m.streams = m.streams;
         std::vector<int> callers;                         // alive caller streams (mode 0)
         std::set<int> all_work;
         int next_work = 0, prev_stream = -1;
         for (int op = 0; op < 100000; op++) {
             const int r = (int)(rng() % 100);
-            if (mode == 0 && r < 12) {                    // the caller creates a stream
-                m.streams.push_back(Mock::S{true, Frontier()}); lazy_m.streams.push_back(Mock::S{true, Frontier()});
+            if (mode != 1 && r < 12) {                    // the caller creates a stream
+                m.streams.push_back(Mock::S{true, m.completed}); lazy_m.streams.push_back(Mock::S{true, Frontier()});
                 callers.push_back((int)m.streams.size() - 1);
                 continue;
             }
-            if (mode == 0 && r < 24 && !callers.empty()) { // ... or destroys one, whatever the context last ran on it
+            if (mode != 1 && r < 24 && !callers.empty()) { // ... or destroys one, whatever the context last ran on it
                 const size_t k = rng() % callers.size();
                 m.streams[callers[k]].alive = false; lazy_m.streams[callers[k]].alive = false;
                 callers.erase(callers.begin() + (long)k);
@@ -87,14 +110,16 @@ int main()
             all_work.insert(next_work++);
             if (g.leave(m, st) != 0) { printf("guard refused a seal\n"); return 1; }
             lazy.enter(lazy_m, st);
-            calls++; foreign_calls += (mode == 0 && st != own); switches += (prev_stream >= 0 && prev_stream != st); prev_stream = st;
+            calls++; foreign_calls += (mode != 1 && st != own); switches += (prev_stream >= 0 && prev_stream != st); prev_stream = st;
             if (all_work.size() > 64) all_work.erase(all_work.begin());   // the invariant is checked against the latest 64 items
         }
         // what a destructor waits for never names a dead stream either
         int which = -1;
         const auto pend = g.pending(&which);
         if (pend == hw::StreamGuard<int>::Pending::OwnedStream && !m.streams[which].alive) m.dead_stream_uses++;
-        printf("mode %d: %ld records, %ld waits, %ld uses of a dead stream\n", mode, m.records, m.waits, m.dead_stream_uses);
+        if (pend == hw::StreamGuard<int>::Pending::DeviceSync) { printf("the guard ended up needing a device synchronisation\n"); return 1; }
+        printf("mode %d: %ld records (%ld failed -> %ld host syncs), %ld waits, %ld uses of a dead stream\n", mode, m.records, m.failed_records, m.syncs, m.waits, m.dead_stream_uses);
+        if (mode == 2 && (m.failed_records < 100 || m.syncs != m.failed_records)) { printf("failure injection did not exercise the fallback\n"); return 1; }
         if (m.dead_stream_uses) { printf("LIFETIME violated\n"); return 1; }
         lazy_dead += lazy_m.dead_stream_uses;
         if (mode == 1 && m.records > switches) { printf("a pipe's context recorded more often than it switched streams\n"); return 1; }

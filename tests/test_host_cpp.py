@@ -2,6 +2,7 @@
 points, without a GPU: sharding, 20-run statistics, control-variate post-processing, theta recovery and the
 reference's file formats (JSON header/array/performance blocks, CSV, raw float32 arrays)."""
 import json
+import re
 import os
 import subprocess
 
@@ -71,7 +72,8 @@ def test_stream_guard_state_machine_against_a_mock_runtime(tmp_path):
     stream/event semantics with caller streams created and destroyed at random (tests/cpp/stream_guard_probe.cpp):
     every enqueue ordered behind all earlier ones, no record/wait ever on a dead stream, a pipe's contexts record only at
     switches -- and round 2's lazy scheme, on the same schedule, does touch dead streams (the use-after-free behind
-    GPUTEST_r02.json's SIGSEGV)."""
+    GPUTEST_r02.json's SIGSEGV).  A third pass makes one record in fifty FAIL: the guard drains that stream on the host,
+    forgets it and goes on (no later call refused, nothing left pending on a stream it cannot name)."""
     exe = str(tmp_path / "stream_guard_probe")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(PKG, "csrc"),
                            os.path.join(ROOT, "tests", "cpp", "stream_guard_probe.cpp"), "-o", exe])
@@ -81,6 +83,7 @@ def test_stream_guard_state_machine_against_a_mock_runtime(tmp_path):
     assert d["order_violations"] == 0 and d["calls"] > 150_000 and d["calls_on_caller_streams"] > 30_000 and d["switches"] > 100_000
     assert d["lazy_scheme_dead_stream_uses"] > 0
     assert "0 uses of a dead stream" in r.stdout and "LIFETIME violated" not in r.stdout
+    assert re.search(r"mode 2: \d+ records \((\d+) failed -> \1 host syncs\)", r.stdout), r.stdout
 
 
 def test_fleet_two_phase_protocol_against_a_mock_collective(tmp_path):
