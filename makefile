@@ -63,9 +63,9 @@ run-benchmark: benchmark
 microbench:
 	@mkdir -p tools/bin
 	$(HIPCC) --offload-arch=gfx950 -O3 tools/valu_rates.hip -o tools/bin/valu_rates
-	$(HIPCC) --offload-arch=gfx950 -O3 tools/valu_patterns.hip -o tools/bin/valu_patterns
-	$(HIPCC) --offload-arch=gfx950 -O3 tools/coissue_probe.hip -o tools/bin/coissue_probe
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I $(PKG)/csrc tools/loop_lab.hip -o tools/bin/loop_lab
+	$(HIPCC) --offload-arch=gfx950 -O3 tools/labs/valu_patterns.hip -o tools/bin/valu_patterns
+	$(HIPCC) --offload-arch=gfx950 -O3 tools/labs/coissue_probe.hip -o tools/bin/coissue_probe
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I $(PKG)/csrc tools/labs/loop_lab.hip -o tools/bin/loop_lab
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I $(PKG)/csrc tools/timeline_probe.hip -o tools/bin/timeline_probe
 
 run-all: run-q1 run-q2 run-q3

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything a round's profiles/ directory is made of, collected on the GPU box in one go:
-#   tools/collect_round.sh r02        (then: python tools/summarize_profile.py gpurun_out/prof_r02 r02, and copy the texts)
+#   tools/collect_round.sh r04        (then: python tools/summarize_profile.py gpurun_out/prof_r04 r04, and copy the texts)
 # Every step runs under its own timeout; a step that fails stops the script (no further GPU work after a failure).
 set -u
 TAG=${1:-r02}
@@ -24,6 +24,9 @@ step "readme pin" 200 python tools/readme_pin_report.py > "$OUT/readme_pin.txt" 
 step "mix bound" 100 tools/bin/mix_bound > "$OUT/mix_bound.txt" 2>&1
 step "mix bound json" 100 tools/bin/mix_bound --json > "$OUT/mix_bound.json" 2>&1
 step "seal cost" 100 python tools/seal_cost_probe.py > "$OUT/seal_cost_probe.txt" 2>&1
+step "clock along the launch" 200 python tools/labs/clock_vs_duration.py > "$OUT/clock_along_the_launch.txt" 2>&1
+step "time-split proxy" 200 python tools/labs/time_split_proxy.py > "$OUT/time_split_proxy.txt" 2>&1
+step "parity envelope" 300 python tools/labs/parity_envelope.py 40 > "$OUT/parity_envelope.txt" 2>&1
 step "throughput cpp" 100 ./bin/throughput --theta-profile readme > "$OUT/throughput_cpp.txt" 2>&1
 ( for k in zbc zbc1 zcb1; do timeout -k 5 60 tools/bin/timeline_probe 20 512 $k || exit 1; done ) > "$OUT/timeline_probe.txt" 2>&1 || { echo "timeline failed"; exit 1; }
 step "bench sizes" 600 python tools/bench_sizes.py > "$OUT/bench_size_table.txt" 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of ALL path kernels for several engine builds on one box: tools/ab_all.sh ROUNDS lib1.so lib2.so ...
+# A/B of ALL path kernels for several engine builds on one box: tools/labs/ab_all.sh ROUNDS lib1.so lib2.so ...
 R=$1; shift
 for ((i = 0; i < R; i++)); do
   for L in "$@"; do

@@ -1,7 +1,7 @@
 """Error statistics of the double engine's exp2 (hw_debug_exp2) against libm, on the GPU."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import hwmc
 hwmc.build_library()
 p = hwmc.default_params("head", precision="f64")

@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, "/root/repo")
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import hwmc
 p = hwmc.default_params("head")
 e = hwmc.HullWhiteEngine(p, device=0)

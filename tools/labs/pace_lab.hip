@@ -10,7 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "mix_bound_body.inc"
+#include "../mix_bound_body.inc"
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 #define LAB_PROLOGUE \

@@ -2,7 +2,7 @@
 the same draws, relative to the f64 oracle, for a = 0.02, 0.1, 0.5 (test infrastructure: uses oracle/)."""
 import sys, numpy as np
 import os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import hwmc, hw_oracle
 for a in (0.02, 0.1, 0.5):
