@@ -68,7 +68,7 @@ int  hw_profile_spans(hw_ctx* ctx, hw_ctx* ref, float* start_ms, float* end_ms, 
 int  hw_get_launch_geometry(hw_ctx* ctx, const char* kernel, int64_t n_units, int32_t* block, int32_t* grid,
                             int32_t* iters, int64_t* partial_bytes);
 /* Shader clock (MHz) the chip held during the last profiled superposed-ZBC or blocked-curve launch, from in-kernel
- * s_memtime / s_memrealtime probes in up to 16 workgroups spread evenly over the grid (= along the launch, workgroups being
+ * s_memtime / s_memrealtime probes in up to 64 workgroups spread evenly over the grid (= along the launch, workgroups being
  * dispatched in index order): the time-weighted mean over the probing workgroups' lifetimes (read after the launch completed). */
 int  hw_profile_clock(hw_ctx* ctx, double* shader_mhz);
 /* The individual probes of that launch: clock (MHz) of each probing workgroup and its entry / exit time in microseconds

@@ -421,12 +421,12 @@ struct WorkgroupStamp {
     }
 };
 
-// Optional clock probe (diagnostic; hw_profile_clock*): up to kClkProbes workgroups spread evenly over the grid -- workgroup
+// Optional clock probe (diagnostic; hw_profile_clock*): up to kClkProbes (64) workgroups spread evenly over the grid -- workgroup
 // j << shift, j < kClkProbes -- store {s_memtime (shader clock), s_memrealtime (100 MHz)} at their entry and exit into
 // clk[4 j .. 4 j + 3].  Workgroups are dispatched in index order, so the probes sample the clock along the whole launch: ONE
 // probe in workgroup 0 (rounds 1-3) saw only the first slot of a launch whose grid is larger than the chip, and the clock
 // of a 40-100 ms launch is not constant (tools/labs/clock_vs_duration.py).  All conditions are wave-uniform scalars.
-constexpr int kClkProbes = 16;
+constexpr int kClkProbes = 64;
 struct ClockProbe {
     __device__ static __forceinline__ bool mine(const unsigned long long* clk, uint32_t shift, uint32_t& j)
     {

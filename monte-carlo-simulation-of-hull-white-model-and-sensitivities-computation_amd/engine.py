@@ -155,9 +155,9 @@ class HullWhiteEngine:
 
     def profile_clock_samples(self):
         """(mhz, start_us, end_us) of every probing workgroup of the last profiled ZBC / blocked-curve launch."""
-        mhz, t0, t1 = (np.zeros(16, np.float64) for _ in range(3))
+        mhz, t0, t1 = (np.zeros(64, np.float64) for _ in range(3))
         n = C.c_int32(0)
-        L.check(self.lib.hw_profile_clock_samples(self._ctx, _dp(mhz), _dp(t0), _dp(t1), 16, C.byref(n)))
+        L.check(self.lib.hw_profile_clock_samples(self._ctx, _dp(mhz), _dp(t0), _dp(t1), 64, C.byref(n)))
         return mhz[:n.value].copy(), t0[:n.value].copy(), t1[:n.value].copy()
 
     def set_launch(self, block_size=0, max_blocks_per_cu=0, table_in_lds=0, pairs_in_flight=0):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Does the in-kernel clock probe of a launch fall with the launch's duration, and do the cycles per block it implies fall
-with it?  Blocked curve kernel (P = 4 forced, grid capped by its wide rows: the clock probes sit in 16 workgroups spread over the grid, i.e. along the launch) and the
+with it?  Blocked curve kernel (P = 4 forced, grid capped by its wide rows: the clock probes sit in up to 64 workgroups spread over the grid, i.e. along the launch) and the
 ZBC kernel with the grid capped at 16 workgroups per CU, 4000-step grid, 2^21..2^26 pairs, 6 launches back to back each."""
 import os
 import sys
