@@ -43,6 +43,65 @@ def test_committed_bench_line_carries_the_claims():
         assert d["timed_region_s"] >= 0.5
 
 
+def _readme_rows():
+    text = open(os.path.join(ROOT, "README.md"), encoding="utf-8").read()
+    block = text.split("<!-- perf-table")[1].split("<!-- /perf-table -->")[0]
+    rows = []
+    for line in block.splitlines():
+        cells = [c.strip() for c in line.strip().strip("|").split("|")]
+        if len(cells) != 4 or not re.search(r"`[a-z0-9_.]+`", cells[3]) or set(cells[1]) <= set("-"):
+            continue
+        keys = re.findall(r"`([A-Za-z0-9_.]+)`", cells[3])
+        ranges = []
+        for part in cells[1].split("/"):
+            nums = [float(x.replace(" ", "").replace("\u202f", "")) for x in re.findall(r"\d[\d \u202f]*(?:\.\d+)?", part)]
+            ranges.append((min(nums), max(nums)))
+        xs = None if cells[2] in ("—", "-", "") else float(cells[2])
+        rows.append((cells[0], ranges, xs, keys))
+    return rows
+
+
+def _lookup(d, dotted):
+    for k in dotted.split("."):
+        d = d[k]
+    return float(d)
+
+
+def test_the_readme_table_is_the_committed_bench_line():
+    """every row of README.md's performance table names a key of the driver-timed bench line; the committed
+    line (profiles/rNN_bench_n1.json, the newest round's) must carry that key with a value inside the README's range (±1 % of
+    slack on both ends: the README rounds), and the '× V100' column must be that value over the reference's published figure.
+    All five BASELINE configs are covered: [0] cpu_baseline.q1_curve + q1_curve_gpu, [1] value, [2] q3_vega_gpu + q3_fd_vega_gpu,
+    [3] strong_scaling_reference, [4] stress."""
+    rnd, d = _newest_bench_line()
+    assert rnd >= 4, "the README table is round 4's: commit profiles/r04_bench_n1.json"
+    rows = _readme_rows()
+    assert len(rows) >= 12
+    published = {"q1_curve_gpu.value": 391.0, "q3_vega_gpu.value": 509.0}
+    for label, ranges, xs, keys in rows:
+        assert len(ranges) == len(keys), (label, ranges, keys)
+        for (lo, hi), key in zip(ranges, keys):
+            v = _lookup(d, key)
+            assert 0.99 * lo <= v <= 1.01 * hi, "README row %r says %g-%g for %s, the committed line has %.1f" % (label, lo, hi, key, v)
+        if xs is not None:
+            v = _lookup(d, keys[0])
+            assert xs == pytest.approx(v / published.get(keys[0], 1064.0), abs=0.06), (label, xs, v)
+    # the configs the table does not list as rates
+    assert d["cpu_baseline"]["q1_curve"]["value"] > 0 and d["cpu_baseline"]["q1_curve"]["cores"] >= 1          # configs[0]
+    ref = d["strong_scaling_reference"]                                                                        # configs[3] on one GPU
+    assert ref["pairs_per_step"] == 1 << 24 and len(ref["sums_step0"]) == 5 and ref["kernel_ms"] > 0
+    st = d["stress"]                                                                                           # configs[4] on one GPU
+    assert st["pairs"] == 1 << 26 and st["grid_steps"] == 4000
+    for prec in ("f32", "f64"):
+        for k in ("zbc", "curve"):
+            x = st[prec][k]
+            assert 0.9 < x["valu"]["frac"] <= 1.03 and x["hbm"]["frac"] < 1e-4, (prec, k, x["valu"], x["hbm"])
+    assert 1.05 < st["f64_over_f32"]["zbc"] < 1.12 and 1.10 < st["f64_over_f32"]["curve"] < 1.17
+    assert [r["pairs_log2"] for r in d["size_table"]["rows"]] == [20, 22, 24, 26]
+    assert 0.84 <= d["q1_curve_gpu"]["valu"]["frac"] <= 1.0 and d["q1_curve_gpu"]["valu"]["loop"] == "curve_f32_p1"
+    assert d["sync_call"]["vs_baseline"] == pytest.approx(d["sync_call"]["value"] / 1064.0, rel=1e-6)
+
+
 @pytest.mark.perf
 def test_live_pipelined_and_synchronous_rates(hwmc_mod):
     import numpy as np
