@@ -287,10 +287,12 @@ def main():
     cdev = "cpu" if rehearsal else dev                 # where the small control tensors of the collectives live
     # a second, host-side group (gloo) for the side measurement "the same pricing call with the sums added on the host"
     host_group = None
-    if dist_on and not rehearsal:
-        try:
-            host_group = dist.new_group(backend="gloo")
-        except Exception:                              # (a build of torch without gloo: the side measurement is skipped)
+    if dist_on and not rehearsal and os.environ.get("HWMC_BENCH_HOST_GROUP", "1") != "0":
+        try:                                           # (every rank takes the same branch: same host, same torch build)
+            import datetime
+            host_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=60))
+        except Exception as exc:                       # a torch without gloo, an interface gloo cannot bind: the side measurement is skipped
+            print("bench.py: no host-side group (%s); multi_gpu.single_call_host_sum_ms will be null" % exc, file=sys.stderr)
             host_group = None
 
     import numpy as np
