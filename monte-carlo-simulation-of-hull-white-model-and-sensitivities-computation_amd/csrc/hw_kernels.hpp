@@ -1368,10 +1368,10 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
             for (int j = 0; j < nblk; j++) {
                 const int ev = to_event <= 2 ? to_event : 0;               // 1: after the first half, 2: after the second
                 float accq;                                                // assigned by q == 0 of an event block
-                auto contribute = [&](int q) {
+                auto contribute = [&](int q, REAL Wq) {
                     float z;
-                    if constexpr (kDouble) z = (float)__builtin_fma(a.c1_d, W[q], -a.c2_d * y[q]);
-                    else z = __builtin_fmaf(c1v, W[q], -c2v * y[q]);
+                    if constexpr (kDouble) z = (float)__builtin_fma(a.c1_d, Wq, -a.c2_d * y[q]);
+                    else z = __builtin_fmaf(c1v, Wq, -c2v * y[q]);
                     const float c = hw_exp2(z) + hw_exp2(-z);              // market_data.cuh:60
                     accq = q == 0 ? live[q] * c : __builtin_fmaf(live[q], c, accq);
                 };
@@ -1382,39 +1382,47 @@ zcb_curve_blocked_kernel(const ZcbBlockedArgs a, double* __restrict__ partials)
                     float s0, sn0, cs0, s1, sn1, cs1;
                     box_muller_parts(w0, w1, s0, sn0, cs0);
                     box_muller_parts(w2, w3, s1, sn1, cs1);
+                    // The event code is compared afresh (scalar, free) for every pair: left to itself the compiler computes
+                    // `ev == 1` once, and -- every v_mad_u64_u32 in between clobbers an SGPR pair with its carry-out -- parks the
+                    // flag in a VECTOR register (v_cndmask + v_cmp per pair: 1 % of the P = 4 loop, seen in the issue-bound twin's trace).
+                    int evq = ev;
+                    asm volatile("" : "+s"(evq));
                     // ev is wave-uniform: these are scalar branches.  The empty volatile asm keeps the compiler from
                     // if-converting them (it did: both pairs of v_exp_f32 ran in every event block and a v_cndmask
                     // picked one -- two transcendentals = 16 issue cycles wasted per maturity).
                     if constexpr (kDouble) {
                         const float t0 = s0 * __builtin_fmaf(e1v, sn0, cs0), t1 = s1 * __builtin_fmaf(e1v, sn1, cs1);
                         const float u0 = s0 * (sn0 + cs0), u1 = s1 * (sn1 + cs1);
-                        if (ev == 1) {                                     // a maturity between the two halves
+                        // W advances by the block's sum of normals ONCE, in place, ahead of the event branches.  (Updated inside them --
+                        // W += u0; contribute; W += u1 in one arm, W += u0 + u1 in the other -- the compiler hoisted the common sum into
+                        // a temporary, because one arm still needed the old W, and paid a v_mov_b64 per pair and block for the copy
+                        // back: issue-bound twin's trace.)  A maturity between the halves reads W - u1; the difference to W_old + u0
+                        // is one rounding of u0 + u1 in float, 1e-7 of a normal, below the float rounding of z that follows.
+                        W[q] += (double)(u0 + u1);
+                        if (evq == 1) {                                    // a maturity between the two halves
                             asm volatile("" ::: "memory");
                             y[q] = __builtin_fma(a.e2_d, y[q], (double)t0);
-                            W[q] += (double)u0;
-                            contribute(q);
+                            contribute(q, W[q] - (double)u1);
                             y[q] = __builtin_fma(a.e2_d, y[q], (double)t1);
-                            W[q] += (double)u1;
                         } else {                                           // whole block, as the double stepper of ou_walk:
                             y[q] = __builtin_fma(a.e2_d, __builtin_fma(a.e2_d, y[q], (double)t0), (double)t1);   // 3 cvt + 2 fma + 1 add
-                            W[q] += (double)(u0 + u1);
-                            if (ev == 2) {
+                            if (evq == 2) {
                                 asm volatile("" ::: "memory");
-                                contribute(q);
+                                contribute(q, W[q]);
                             }
                         }
                     } else {
                         y[q] = __builtin_fmaf(e2v, y[q], s0 * __builtin_fmaf(e1v, sn0, cs0));
                         W[q] = __builtin_fmaf(s0, sn0 + cs0, W[q]);
-                        if (ev == 1) {
+                        if (evq == 1) {
                             asm volatile("" ::: "memory");
-                            contribute(q);
+                            contribute(q, W[q]);
                         }
                         y[q] = __builtin_fmaf(e2v, y[q], s1 * __builtin_fmaf(e1v, sn1, cs1));
                         W[q] = __builtin_fmaf(s1, sn1 + cs1, W[q]);
-                        if (ev == 2) {
+                        if (evq == 2) {
                             asm volatile("" ::: "memory");
-                            contribute(q);
+                            contribute(q, W[q]);
                         }
                     }
                 }
