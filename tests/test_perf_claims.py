@@ -98,7 +98,7 @@ def test_the_readme_table_is_the_committed_bench_line():
         for k in ("zbc", "curve"):
             x = st[prec][k]
             assert 0.9 < x["valu"]["frac"] <= 1.03 and x["hbm"]["frac"] < 1e-4, (prec, k, x["valu"], x["hbm"])
-    assert 1.05 < st["f64_over_f32"]["zbc"] < 1.12 and 1.10 < st["f64_over_f32"]["curve"] < 1.17
+    assert 1.05 < st["f64_over_f32"]["zbc"] < 1.12 and 1.07 < st["f64_over_f32"]["curve"] < 1.14
     assert [r["pairs_log2"] for r in d["size_table"]["rows"]] == [20, 22, 24, 26]
     assert 0.84 <= d["q1_curve_gpu"]["valu"]["frac"] <= 1.0 and d["q1_curve_gpu"]["valu"]["loop"] == "curve_f32_p1"
     assert d["sync_call"]["vs_baseline"] == pytest.approx(d["sync_call"]["value"] / 1064.0, rel=1e-6)
