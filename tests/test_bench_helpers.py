@@ -56,3 +56,40 @@ def test_world_size_mismatch_and_missing_gpu_fail_loudly():
     if not torch.cuda.is_available():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 2 and "no CPU fallback" in r.stderr and not r.stdout.strip()
+
+
+def test_check_scaling_cli_on_driver_shaped_records(tmp_path):
+    """tools/check_scaling.py takes the driver's records (the line under "parsed", several runs in one file) and runs
+    hwmc.parallel.check_scaling_lines on every N > 1 line against the N = 1 line: here the committed N = 1 line and an 8-GPU
+    line synthesised from it (same sums -> passes; one sum off by 1e-9 -> exit code 1 with the reason)."""
+    import copy
+    import glob
+    d = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1.json")))[-1]))
+    ref = d["strong_scaling_reference"]
+    n8 = copy.deepcopy(d)
+    n8.update(n_gpus=8, ms_per_step=0.36, value=2 * (1 << 24) / 0.36 / 1000.0, sums_step0=list(ref["sums_step0"]))
+    n8["config"].update(pairs_per_step=1 << 24, effective_paths=2 << 24)
+    n8["multi_gpu"] = {"world_size_seen": {"dist": 8, "allreduce_of_ones": 8}, "per_rank_kernel_ms": [0.355] * 8,
+                       "exposed_allreduce_ms_per_step": 0.004, "launch_skew": {"median_ms": 0.003}, "single_call_ms": 0.41,
+                       "single_call_host_sum_ms": 0.39}
+    one, many, bad = (str(tmp_path / n) for n in ("bench.json", "scale.json", "bad.json"))
+    json.dump({"parsed": d, "rc": 0}, open(one, "w"))
+    json.dump({"runs": [{"n": 8, "parsed": n8}]}, open(many, "w"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_scaling.py"), one, many], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rep = json.loads(r.stdout.splitlines()[-1])
+    assert rep["n_gpus"] == 8 and rep["verdict"].startswith("scales") and rep["strong_scaling"] > 7.0
+    n8["sums_step0"][2] *= 1.0 + 1e-9
+    json.dump({"runs": [{"n": 8, "parsed": n8}]}, open(bad, "w"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_scaling.py"), one, bad], capture_output=True, text=True)
+    assert r.returncode == 1 and "did not price the N = 1 sample set" in r.stdout
+
+
+def test_tools_and_labs_compile():
+    """every Python tool and lab at least byte-compiles (the labs are not run by any test: they are records of experiments)"""
+    import glob
+    import py_compile
+    files = glob.glob(os.path.join(ROOT, "tools", "*.py")) + glob.glob(os.path.join(ROOT, "tools", "labs", "*.py"))
+    assert len(files) > 30
+    for f in files:
+        py_compile.compile(f, doraise=True)
