@@ -120,32 +120,22 @@ int  hw_set_market(hw_ctx* ctx, const float* P, const float* f, int32_t n_mat);
 
 /* ---- hot path -------------------------------------------------------------------------- */
 /* out[5] = {sum X, sum Y, sum X^2, sum Y^2, sum XY} over 2*n_pairs samples (double).
- * kernel_ms (may be NULL): hipEvent time of the launch(es), as 2_option:131-144 measures it.
- * All synchronous entry points (this one, _runs, _scenarios, hw_zcb_curve, hw_vega_pathwise*): the column pass stores
- * the results straight into pinned host memory.  With kernel_ms = NULL no event pair is recorded and the call returns
- * the moment its results have landed: the host polls completion stamps the column pass writes behind them (for at
- * most ~300 us, then it falls back to hipStreamSynchronize; HWMC_SPIN_WAIT=0 disables the polling) -- 0.1955 instead
- * of 0.2019 ms per 2^20-pair call, profiles/r03_sync_call_probe.txt.  With kernel_ms the call records the pair and waits
- * for the stream, as before. */
+ * kernel_ms (may be NULL): hipEvent time of the launch(es), as 2_option:131-144 measures it.  With kernel_ms = NULL
+ * (all synchronous entry points) no event pair is recorded and the call returns the moment its results have landed in
+ * pinned host memory (polled completion stamps, ~300 us at most, then hipStreamSynchronize; HWMC_SPIN_WAIT=0: always
+ * the latter). */
 int  hw_zbc_moments(hw_ctx* ctx, const hw_zbc_request* req, double out[5], float* kernel_ms);
 
-/* Same, enqueue only: results land in d_out (DEVICE pointer, 5 doubles) in stream order on
- * `stream` (a hipStream_t; NULL = the context's stream).
- * Streams and the context's workspaces.  Every launch of a context reuses the context's device workspaces
- * (partial sums, tables), in stream order.  Calls on ONE stream pipeline freely.  A call on a different stream
- * than the context's previous call is still correct: its stream is first made to wait, on the device, for
- * everything the context has enqueued before (an event, no host wait) -- so two streams never overlap through
- * one context.  For overlap use one context per stream (bench.py does).
- * Stream lifetime.  A stream passed to an *_async call must be alive for the duration of THAT CALL, nothing more: the
- * library never touches a caller's stream handle after the call that received it has returned.  (What a later call
- * on another stream, or hw_destroy, waits for is an event of the context, recorded on the caller's stream at the end
- * of the call that used it: one hipEventRecord per *_async call on a caller's stream, none on the context's own
- * stream.)  The caller may therefore synchronise and destroy its stream at any time after the call, before or after
- * hw_destroy.  Destroying a stream that still has work of the context in flight is the caller's business, as with
- * any HIP work: hipStreamDestroy lets that work finish.  Host blocking: none in the steady
- * state; the call may block the HOST only when it has to grow the workspace (hipMalloc, first call at a larger
- * size -- the outgrown buffer is released later, never under running kernels) or when four table uploads of
- * this context are still in flight (pinned staging ring). */
+/* Same, enqueue only: results land in d_out (DEVICE pointer, 5 doubles) in stream order on `stream` (a hipStream_t;
+ * NULL = the context's stream).  Rules for every *_async call:
+ *   - workspaces: a context reuses its device workspaces in stream order.  Calls on ONE stream pipeline freely; a call
+ *     on a different stream than the context's previous call first waits, on the device, for the context's earlier
+ *     work -- correct, but serial.  For overlap use one context per stream (or hw_pipe_*).
+ *   - stream lifetime: `stream` must be alive for the duration of THIS CALL, nothing more.  The library never touches a
+ *     caller's stream handle after the call returns (it waits on an event of its own, recorded at the end of the call:
+ *     one hipEventRecord per call on a caller's stream, none on the context's own).
+ *   - host blocking: none in the steady state; only to grow the workspace (first call at a larger size) or when four
+ *     table uploads of this context are still in flight. */
 int  hw_zbc_moments_async(hw_ctx* ctx, const hw_zbc_request* req, double* d_out, void* stream);
 
 /* n_runs independent pricings in ONE launch: run k uses seed + k*seed_stride on the same pairs
@@ -192,20 +182,16 @@ int  hw_vega_pathwise_runs(hw_ctx* ctx, int64_t n_paths, uint64_t seed, uint64_t
 int  hw_sample_paths(hw_ctx* ctx, int32_t n, uint64_t seed, uint64_t path_offset, float* out);
 
 /* ---- a stream of independent pricing calls on ONE GPU, two queues in flight -------------------------
- * (not in the reference: its 20-run validation launches, synchronises and copies 20 times, src/2_option_pricing.cu:225-302).
- * A launch of 2^20 pairs spends ~4 us of its ~187 us outside its waves (dispatch, end-of-kernel release) and ~11 us
- * draining through a thinning last round of waves; a second launch in flight on another hardware queue fills both.  A pipe owns
- * n_queues contexts (each with its own workspaces) and a set of candidate streams; HIP maps streams onto a few hardware
- * queues in a way that depends on the process's history, and two streams that share a queue serialise, so hw_pipe_tune
- * times every pair of candidates on the caller's own workload and keeps the fastest (hw_pipe_zbc_moments tunes on its
- * first request if the caller has not).  hw_pipe_zbc_moments enqueues the n requests alternating over the queues -- every
- * request is one full pricing call, exactly hw_zbc_moments_async, whose column pass stores its five sums straight into
- * pinned host memory -- and synchronises once; the sums equal those of n separate hw_zbc_moments calls bit for bit.  wall_ms: host wall time of the
- * call.  Measured at 2^20 pairs x 500 steps: 0.172 ms per call against 0.201 ms for synchronous hw_zbc_moments calls one after another.
- * Like a context, a pipe is used by one host thread at a time; a request the engine refuses fails the whole batch before
- * anything is enqueued (HIP errors surfacing later leave nothing in flight either: the call synchronises the device).
- * hw_pipe_zbc_moments on an untuned pipe tunes first on a copy of reqs[0] capped at 2^20 pairs, 8 launches per trial
- * (~0.1 s once, not part of wall_ms); call hw_pipe_tune yourself to keep that out of the first pricing call. */
+ * (not in the reference: its 20-run validation launches, synchronises and copies 20 times, 2_option:225-302).
+ * A pipe owns n_queues contexts and a set of candidate streams.  hw_pipe_zbc_moments enqueues the n requests alternating
+ * over the queues -- each one full pricing call, exactly hw_zbc_moments_async -- and synchronises once: a second launch
+ * in flight covers the first one's drain and launch gaps.  The sums equal those of n separate
+ * hw_zbc_moments calls bit for bit.  wall_ms: host wall time of the call.
+ * HIP maps streams onto a few hardware queues unpredictably and two streams that share one serialise: hw_pipe_tune times
+ * every pair of candidates on the caller's workload and keeps the fastest.  An untuned pipe tunes inside its first
+ * hw_pipe_zbc_moments (on a copy of reqs[0] capped at 2^20 pairs, ~0.1 s, not part of wall_ms).
+ * One host thread at a time; a request the engine refuses fails the whole batch before anything is enqueued, and an
+ * error surfacing later leaves nothing in flight (the call synchronises the device). */
 typedef struct hw_pipe hw_pipe;
 int  hw_pipe_create(const hw_params* p, int device, int32_t n_queues /* 1..4 */, hw_pipe** out);
 void hw_pipe_destroy(hw_pipe* pipe);
@@ -215,23 +201,18 @@ int  hw_pipe_tune(hw_pipe* pipe, const hw_zbc_request* sample, int32_t launches 
 int  hw_pipe_zbc_moments(hw_pipe* pipe, const hw_zbc_request* reqs, int32_t n, double* out /* [n][5] */, float* wall_ms);
 
 /* ---- several GPUs in one process ---------------------------------------------------------------
- * (not in the reference, which is single-GPU).  A communicator spans contexts created on DIFFERENT
- * devices with identical parameters and market curves.  Each call shards the paths by global id
- * (context g gets a contiguous block); one persistent host thread per device (started by hw_comm_create)
- * enqueues that device's shard and ONE ncclAllReduce on the device's stream (RCCL over xGMI; librccl.so.1 is
- * loaded at hw_comm_create, the library itself does not link it) and waits for it.  wall_ms: host wall time from the first launch to the reduced result.
- * Errors: a request is checked against EVERY context on the calling thread before any device is given work.  What
- * only one device can find out at run time (workspace growth, table upload, launch geometry, a launch error) is caught
- * by a two-phase job: every worker first enqueues its shard's kernels, the workers meet, and the all-reduce is entered
- * only if ALL of them succeeded -- otherwise nobody enters it, every device drains, the call returns "device <id>:
- * <text>" of the failing rank through hw_last_error() and the communicator stays usable.  A failure after that point
- * (inside the collective or the synchronisation behind it) aborts every communicator (ncclCommAbort, which releases
- * ranks blocked in the collective): the call returns the error of the rank that failed FIRST (the culprit -- not of a
- * lower-ranked victim whose own calls then failed because of the abort) and every later call on this hw_comm is refused;
- * destroy it and create a new one.  [That abort path has run with ONE rank only (no multi-GPU box was available to the
- * authoring rounds); its host protocol is checked with 2, 3 and 8 workers against a mock collective under ThreadSanitizer,
- * tests/cpp/fleet_probe.cpp, but ncclCommAbort from a peer's worker thread has never executed with G > 1.]  HWMC_COMM_INJECT_FAIL=rank:phase[:count] (read by hw_comm_create*) makes rank
- * `rank` fail in phase 1 or 2 of its next `count` jobs: the rehearsal tests' switch, not for production. */
+ * (not in the reference, which is single-GPU).  A communicator spans contexts created on DIFFERENT devices with identical
+ * parameters and market curves.  Each call shards the paths by global id (context g gets a contiguous block); one
+ * persistent host thread per device enqueues that device's shard and ONE ncclAllReduce on the device's stream (RCCL over
+ * xGMI; librccl.so.1 is dlopen'ed by hw_comm_create) and waits for it.  wall_ms: first launch to reduced result.
+ * Errors.  A request is checked against every context before any device is given work.  What only one device can find out
+ * at run time is caught by a two-phase job: the all-reduce is entered only if ALL workers enqueued their kernels --
+ * otherwise nobody enters it, the call returns "device <id>: <text>" of the failing rank and the communicator stays
+ * usable.  A failure inside the collective aborts every communicator (ncclCommAbort): the call returns the error of the
+ * rank that failed FIRST (not of a victim of the abort) and later calls on this hw_comm are refused; destroy it.
+ * [That abort path has run with ONE rank only -- no multi-GPU box was available; its host protocol is checked with up to
+ * 8 workers against a mock collective under ThreadSanitizer, tests/cpp/fleet_probe.cpp.]
+ * HWMC_COMM_INJECT_FAIL=rank:phase[:count] (read by hw_comm_create*): failure injection for the rehearsal tests. */
 typedef struct hw_comm hw_comm;
 int  hw_comm_create(int32_t n, hw_ctx* const* ctxs, hw_comm** out);
 /* The same with a choice of how the shards' sums are combined: HW_COMM_RCCL (what hw_comm_create does) or
