@@ -44,8 +44,8 @@ instruction stream with its data dependencies removed (tools/gen_mix_bound.py) i
 SIMD issues that instruction mix in the production ORDER when nothing waits for a result.  It is the fastest of the orderings
 and occupancies tried, not a proven floor (the provable one, `exclusive_classes_floor`, is lower); valu.frac = bound / achieved
 is the share of a launch's SIMD time that the loop's issue rate accounts for -- the rest is prologue, epilogue, drain and
-dependency stalls.  Loops with a twin: the float ZBC/Vega loop, the double ZBC loop, the curve loop (P = 1 and P = 4 pairs per
-thread, float and double).  bench.py runs the probe live (a child process, before this process touches the GPU) when
+dependency stalls.  Loops with a twin: the float ZBC/Vega loop, the double ZBC loop, the curve loop (P = 1 pair per thread on
+the 1000-step grid; P = 2 on the 4000-step grid, float and double).  bench.py runs the probe live (a child process, before this process touches the GPU) when
 tools/bin/mix_bound exists, else reads the newest profiles/rNN_mix_bound.json.
 """
 import argparse
@@ -213,7 +213,7 @@ def mix_bound(live=True):
 
 def loop_bound(bound, name):
     """cycles per Philox block per SIMD of the dependency-free twin of loop `name` ("zbc_f32", "zbc_f64", "curve_f32_p1",
-    "curve_f32_p4", "curve_f64_p4"; tools/mix_bound.hip `loops`), or None when the probe result does not carry it."""
+    "curve_f32_p2", "curve_f64_p2"; tools/mix_bound.hip `loops`), or None when the probe result does not carry it."""
     if not bound:
         return None
     if name == "zbc_f32":
@@ -819,7 +819,7 @@ def main():
                             mhz_ = clock_of(es)
                             g_ = es.launch_geometry(geo_name, nS)
                             bytes_ = g_["partial_bytes"] + (5 if kname == "zbc" else ps.n_mat) * 8
-                            loop = ("zbc_" + prec) if kname == "zbc" else ("curve_%s_p4" % prec)
+                            loop = ("zbc_" + prec) if kname == "zbc" else ("curve_%s_p2" % prec)
                             ent[kname] = {"kernel_ms": ms_, "kernel_ms_all": msl, "value": (2 * nS / ms_) / 1000.0, "unit": "M paths/s",
                                           "thread_steps_per_sec": nS * steps_ / (ms_ * 1e-3),
                                           "hbm": {"algorithmic_bytes_per_launch": bytes_, "achieved_GBps": bytes_ / (ms_ * 1e-3) / 1e9,

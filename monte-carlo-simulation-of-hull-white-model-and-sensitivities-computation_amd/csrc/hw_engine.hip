@@ -502,16 +502,20 @@ int launch_zcb(hw_ctx* c, int64_t n_pairs, uint64_t seed, uint64_t path_offset, 
         c->scale_valid = true;
     }
 
-    // whole Philox blocks, maturities on half-block boundaries: the blocked kernel, P pairs per thread
-    // (P = 4 / 2 once the batch still fills the chip's 8 waves per SIMD twice over: measured, one round of fat
-    // threads is no faster than two rounds of thin ones)
+    // whole Philox blocks, maturities on half-block boundaries: the blocked kernel, P pairs per thread.
+    // P = 2 from eight chip-fills of pairs (2^22 on 256 CUs), else 1: re-measured in round 4 after the curve loop lost its
+    // two compiler artefacts (tools/labs/curve_p_now.py, profiles/r04_curve_p_scan.txt: 1000- and 4000-step grids, float and
+    // double, 2^20 .. 2^26 pairs).  P = 2 halves the per-maturity reductions per pair and wins by 0.3-1.8 % from 2^22 pairs
+    // up; below, the longer waves cost more in the drain than the reductions save.  P = 4 -- rounds 2-3's choice from 2^22
+    // -- is never the fastest any more (2.4 % behind P = 2 at 2^22, 0.2-0.8 % at 2^26); the instance is kept for
+    // HWMC_CURVE_P and the tests.
     // (in float the (y, W) form needs (1 - e) sqrt(n_steps) >= 0.05, see ou_walk; in double the division is harmless)
     constexpr bool kDouble = std::is_same<REAL, double>::value;
     if (p.n_steps % 4 == 0 && stride % 2 == 0 && stride >= 4 && !c->curve_generic &&
         (kDouble || (1.0 - (double)(float)k.e) * std::sqrt((double)p.n_steps) >= 0.05)) {
         const int64_t resident = (int64_t)c->prop.multiProcessorCount * 2048;
-        int P = n_pairs >= 8 * resident ? 4 : n_pairs >= 4 * resident ? 2 : 1;   // keep >= 2 rounds of waves
-        if (const char* m = getenv("HWMC_CURVE_P")) { const int v = atoi(m); if (v == 1 || v == 2 || v == 4) P = v; }   // tools/curve_p_probe.py
+        int P = n_pairs >= 8 * resident ? 2 : 1;
+        if (const char* m = getenv("HWMC_CURVE_P")) { const int v = atoi(m); if (v == 1 || v == 2 || v == 4) P = v; }   // tools/labs/curve_p_now.py
         const Geometry g = geometry(c, n_pairs, P, true);
         int rc = ensure_partials(c, (size_t)g.grid * n_mat);
         if (rc) return rc;
@@ -1165,7 +1169,7 @@ int hw_get_launch_geometry(hw_ctx* c, const char* kernel, int64_t n_units, int32
         int P = 1;
         if (!strcmp(kernel, "zcb_blocked")) {
             const int64_t resident = (int64_t)c->prop.multiProcessorCount * 2048;
-            P = n_units >= 8 * resident ? 4 : n_units >= 4 * resident ? 2 : 1;
+            P = n_units >= 8 * resident ? 2 : 1;
         }
         g = geometry(c, n_units, P, true);
         row = (int64_t)c->p.n_mat * 8;

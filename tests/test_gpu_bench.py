@@ -90,7 +90,7 @@ def test_bench_default_line_carries_the_side_measurements():
     assert sc["calls"] == 20 and sc["ms_per_call"] >= d["roofline"]["kernel_ms_min"] and sc["value"] > 1064.0
     st = d["stress"]
     for prec in ("f32", "f64"):
-        for k, loop in (("zbc", "zbc_" + prec), ("curve", "curve_%s_p4" % prec)):
+        for k, loop in (("zbc", "zbc_" + prec), ("curve", "curve_%s_p2" % prec)):
             x = st[prec][k]
             assert x["value"] > 0 and x["hbm"]["frac"] < 1e-3 and x["valu"]["loop"] == loop and 0.5 < x["valu"]["frac"] <= 1.03, (prec, k, x)
     assert 1.0 < st["f64_over_f32"]["zbc"] < 1.3 and 1.0 < st["f64_over_f32"]["curve"] < 1.3

@@ -536,10 +536,15 @@ def test_zcb_curve_blocked_kernel_variants(hwmc_mod, oracle_mod, monkeypatch):
     g = hwmc_mod.HullWhiteEngine(p, device=0)
     monkeypatch.delenv("HWMC_CURVE_GENERIC")
     cus = e.device_info()["compute_units"]
-    for n in (1000, 4 * 2048 * cus + 77, 8 * 2048 * cus + 5):                      # P = 1, 2, 4 (ragged counts)
+    for n in (1000, 4 * 2048 * cus + 77, 8 * 2048 * cus + 5):                      # P = 1, 1, 2 by the engine's rule (ragged counts)
         got = e.simulate_zcb(n, 11)
         assert got[0] == 2.0 * n
         np.testing.assert_allclose(got, g.simulate_zcb(n, 11), rtol=2e-6)           # two float evaluation orders
+        for forced in ("1", "2", "4"):                                             # ... and every P forced at every size class
+            monkeypatch.setenv("HWMC_CURVE_P", forced)
+            np.testing.assert_allclose(e.simulate_zcb(n, 11), got, rtol=2e-6, err_msg="P = %s, n = %d" % (forced, n))
+        monkeypatch.delenv("HWMC_CURVE_P")
+        assert e.launch_geometry("zcb_blocked", n)["units_per_thread"] == (2 if n >= 8 * 2048 * cus else 1)
         if n <= 4 * 2048 * cus + 77:
             np.testing.assert_allclose(got, o.zcb_curve(n, 11), rtol=REL_F32)
         half = n // 2                                                              # shards add up (other P per shard)

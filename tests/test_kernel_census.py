@@ -271,7 +271,7 @@ def test_the_other_two_production_loops_have_twins_of_their_own():
         levels = sorted(k[1] for k in kinds if k[0])
         assert levels == sorted(min(4, (~m & (m + 1)).bit_length() - 1) for m in range(1, 17))   # trailing ones of m & 15, capped at 4
         assert sum(k[2] for k in kinds) == 1
-    for name, P, n_trips, n_events in (("CURVE1", 1, 40, 16), ("CURVE4", 4, 160, 16), ("CURVE4_F64", 4, 160, 16)):
+    for name, P, n_trips, n_events in (("CURVE1", 1, 40, 16), ("CURVE2", 2, 160, 16), ("CURVE2_F64", 2, 160, 16)):
         lines = body(name)
         assert re.search(r"#define MIX_BLOCKS_%s %d\n" % (name, n_trips * P), committed)
         assert not [l for l in lines if l.startswith(("ds_", "s_waitcnt", "s_bitcmp"))]
@@ -304,7 +304,7 @@ def test_the_other_two_production_loops_have_twins_of_their_own():
     # and the curve loops cost more than the ZBC loop they contain
     import json
     loops = json.load(open(os.path.join(ROOT, "profiles", "r04_mix_bound.json")))["loops"]
-    assert set(loops) >= {"zbc_f32", "zbc_f64", "curve_f32_p1", "curve_f32_p4", "curve_f64_p4"}
+    assert set(loops) >= {"zbc_f32", "zbc_f64", "curve_f32_p1", "curve_f32_p2", "curve_f64_p2"}
     assert abs(loops["zbc_f64"]["real_loop_cycles_per_block"] - loops["zbc_f64"]["bound_cycles_per_block"]) < 1.0
-    assert loops["zbc_f32"]["bound_cycles_per_block"] < loops["curve_f32_p4"]["bound_cycles_per_block"] < loops["curve_f32_p1"]["bound_cycles_per_block"]
-    assert loops["zbc_f32"]["bound_cycles_per_block"] < loops["zbc_f64"]["bound_cycles_per_block"] < loops["curve_f64_p4"]["bound_cycles_per_block"]
+    assert loops["zbc_f32"]["bound_cycles_per_block"] < loops["curve_f32_p2"]["bound_cycles_per_block"] < loops["curve_f32_p1"]["bound_cycles_per_block"]
+    assert loops["zbc_f32"]["bound_cycles_per_block"] < loops["zbc_f64"]["bound_cycles_per_block"] < loops["curve_f64_p2"]["bound_cycles_per_block"]

@@ -29,9 +29,9 @@ Variants (each a C string macro MIX_BODY_<NAME>, with MIX_BLOCKS_<NAME> Philox b
   REAL1 / REAL2          the production loops VERBATIM (real registers, real dependencies): the calibration that the harness
                          reproduces the production loop's own rate
   F64_1 / F64_1_NOPRIO / REALF64_1   the same three for the DOUBLE ZBC loop, zbc_superposed_kernel<double,1,1> (family zbc_f64)
-  CURVE1 / CURVE4 / CURVE4_F64       the loop of zcb_curve_blocked_kernel<1,float> on the 1000-step grid (BASELINE configs[0]: a maturity
-                         every 2.5 Philox blocks) and of <4,float> / <4,double> on the 4000-step grid (configs[4]: every 10 blocks), maturity
-                         events and the MaturityTree butterfly included (families curve_f32_p1, curve_f32_p4, curve_f64_p4).  That
+  CURVE1 / CURVE2 / CURVE2_F64       the loop of zcb_curve_blocked_kernel<1,float> on the 1000-step grid (BASELINE configs[0]: a maturity
+                         every 2.5 Philox blocks) and of <2,float> / <2,double> on the 4000-step grid (configs[4]: every 10 blocks), maturity
+                         events and the MaturityTree butterfly included (families curve_f32_p1, curve_f32_p2, curve_f64_p2).  That
                          loop has wave-uniform control flow (no event / event after the first half / after the second; 0-4 butterfly
                          levels; the flush of every sixteenth maturity), so its twin is built from TRACES: the scalar compares and
                          branches of the listing are resolved by a small scalar emulator (ScalarEmu) seeded with the registers the
@@ -688,12 +688,12 @@ def generate(search=0):
         family[nm] = "zbc_f64"
     curve_census = {}
     for nm, pattern, n_steps, fam in (("CURVE1", "zcb_curve_blocked_kernelILi1EfE", 1000, "curve_f32_p1"),
-                                      ("CURVE4", "zcb_curve_blocked_kernelILi4EfE", 4000, "curve_f32_p4"),
-                                      ("CURVE4_F64", "zcb_curve_blocked_kernelILi4EdE", 4000, "curve_f64_p4")):
+                                      ("CURVE2", "zcb_curve_blocked_kernelILi2EfE", 4000, "curve_f32_p2"),
+                                      ("CURVE2_F64", "zcb_curve_blocked_kernelILi2EdE", 4000, "curve_f64_p2")):
         lines, blocks, census, groups = curve_variant(text, pattern, n_steps)
         variants[nm] = (lines, blocks)
         family[nm] = fam
-        # one trip = a whole period (40 / 640 pair-blocks): the deadline is checked every trip, and the window is stretched so
+        # one trip = a whole period (40 / 320 pair-blocks): the deadline is checked every trip, and the window is stretched so
         # that the overshoot of the last trip stays ~1 % of it
         meta[nm] = (0, 1 if blocks <= 64 else 6)
         curve_census[nm] = (census, blocks, groups)
@@ -709,7 +709,7 @@ def generate(search=0):
     for name, (lines, blocks) in variants.items():
         emit(name, lines, blocks, fh, census_of(lines) if name not in curve_census else curve_census[name][0])
     full = {"PROD1", "PROD1_NOPRIO", "PROD2", "PROD2_NOPRIO", "GROUPED", "GROUPED_PRIO", "REAL1", "REAL2", "REAL1_HI",
-            "F64_1", "F64_1_NOPRIO", "REALF64_1", "CURVE1", "CURVE4", "CURVE4_F64"}
+            "F64_1", "F64_1_NOPRIO", "REALF64_1", "CURVE1", "CURVE2", "CURVE2_F64"}
     # X(name, dependency-free, full mix, family, deadline-check mask (trips), window scale)
     fh.write("#define MIX_VARIANTS(X) \\\n" + " \\\n".join(
         "    X(%s, %d, %d, \"%s\", %d, %d)" % (name, 0 if name.startswith("REAL") else 1, 1 if name in full else 0, family[name],

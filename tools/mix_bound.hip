@@ -42,7 +42,7 @@
     "s_memrealtime s[80:81]\n\ts_memtime s[76:77]\n\ts_waitcnt lgkmcnt(0)\n\t" \
     "1:\n\t"
 // MASK: the deadline is looked at every (MASK + 1) trips -- 15 for the one- and two-block loops; 0 for the curve twins, whose
-// trip is a whole period of sixteen maturities (40 or 640 pair-blocks)
+// trip is a whole period of sixteen maturities (40 or 320 pair-blocks)
 #define MIX_EPILOGUE(MASK) \
     "s_add_u32 s38, s38, 1\n\ts_and_b32 s39, s38, " #MASK "\n\ts_cmp_lg_u32 s39, 0\n\ts_cbranch_scc1 1b\n\t" \
     "s_memrealtime s[82:83]\n\ts_waitcnt lgkmcnt(0)\n\t" \
