@@ -889,8 +889,9 @@ def main():
         wave_blocks = waves * (steps_exec / 4.0)            # a "block" = one Philox block (4 steps) of the 64 pairs of a wave
         cyc_of = lambda ms: ms * 1e-3 * mhz * 1e6 * info["compute_units"] * 4 / wave_blocks
         achieved_cyc, achieved_cyc_iso = cyc_of(region_per_step), cyc_of(kiso)
-        use_bound = bound if (bound and a.stepper == "superposed" and a.precision == "f32") else None
-        bcyc = use_bound["bound_cycles_per_block"] if use_bound else None
+        use_bound = bound if (bound and a.stepper == "superposed") else None
+        bcyc = loop_bound(use_bound, "zbc_" + a.precision)           # the float or the double loop's own twin
+        f64_twin = ((use_bound or {}).get("loops") or {}).get("zbc_f64") if a.precision == "f64" else None
         if world == 1:
             workload = ("Q2b option_pricing (BASELINE configs[1]): 2^%d antithetic pairs x %d-step grid (%d executed to S1=5), "
                         "optimal-beta control variate, 1 x MI355X" % (a.paths_log2, a.grid_steps, steps_exec))
@@ -954,10 +955,11 @@ def main():
                      "instr_per_4_steps": vm,
                      "bound_cycles_per_block": bcyc,
                      "bound_source": use_bound["source"] if use_bound else None,
-                     "bound_at": use_bound.get("bound_at") if use_bound else None,
+                     "bound_at": (f64_twin or use_bound).get("bound_at") if use_bound else None,
                      "exclusive_classes_floor": ({"nominal_4_4_8": use_bound["exclusive_classes_nominal_floor"],
-                                                  "measured": use_bound["exclusive_classes_measured"]} if use_bound else None),
-                     "production_loop_in_the_harness_cycles": use_bound.get("real_loop_cycles_per_block") if use_bound else None,
+                                                  "measured": use_bound["exclusive_classes_measured"]} if use_bound and a.precision == "f32" else None),
+                     "production_loop_in_the_harness_cycles": ((f64_twin or {}).get("real_loop_cycles_per_block") if a.precision == "f64"
+                                                               else use_bound.get("real_loop_cycles_per_block")) if use_bound else None,
                      "achieved_cycles_per_block_isolated_launch": achieved_cyc_iso,
                      "achieved_cycles_per_block_timed_region": achieved_cyc,
                      "frac": (bcyc / achieved_cyc_iso) if bcyc else None,

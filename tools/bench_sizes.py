@@ -30,7 +30,7 @@ def main():
         v = d["valu"]
         print("stress 2^26 pairs x 4000-step grid, %s: %.2f ms/step, %.0f M paths/s, achieved %.1f cycles per block (isolated launch), bound/achieved %s; clock %.0f MHz"
               % (prec, d["ms_per_step"], d["value"], v["achieved_cycles_per_block_isolated_launch"],
-                 ("%.3f" % v["frac"]) if v["frac"] else "n/a (the measured bound is the float loop's)", v["clock_mhz_in_kernel"] or 0), flush=True)
+                 ("%.3f" % v["frac"]) if v["frac"] else "n/a (no bound for this loop in the probe result)", v["clock_mhz_in_kernel"] or 0), flush=True)
 
 
 if __name__ == "__main__":
