@@ -344,7 +344,7 @@ def main():
         # torch's RCCL backend runs every collective on a stream of its own, which it makes wait for an event of the
         # stream that is CURRENT at the call; the caller's stream only waits for the collective in Work.wait().  So no
         # compute stream ever waits for RCCL.  One producer (the per-call default): issue it with the producer's stream
-        # current -- one event hop; measured 2 % cheaper than going through a side stream (tools/allreduce_cost_probe.py:
+        # current -- one event hop; measured 2 % cheaper than going through a side stream (tools/labs/allreduce_cost_probe.py:
         # 12 159 plain, 11 910 this way, 11 729 through a side stream, one-rank communicator).  Several producers (a
         # message of several steps): a side stream joins them first.
         if len(on_streams) == 1:
@@ -357,7 +357,7 @@ def main():
 
     # Explicit side streams: step i runs on streams[i % S], handed to the C ABI as a raw hipStream_t.
     # HIP multiplexes its streams onto a few hardware queues (4 here) and two streams that share a queue
-    # serialise (tools/queue_map_probe.py: which streams share one depends on the creation history of the whole
+    # serialise (tools/labs/queue_map_probe.py: which streams share one depends on the creation history of the whole
     # process).  So take 8 candidate streams and keep those that run the workload fastest together --
     # with the per-step all-reduce in the loop when there is one, so that the queue RCCL's stream landed on counts.
     cands = [torch.cuda.Stream(device=dev) for _ in range(8 if S > 1 else 1)]
@@ -609,7 +609,7 @@ def main():
     if world == 1 and not a.no_extras and S > 1:
         # The same alternation over 10 K steps in ONE region: what the two edges of a K-step region cost.  After a
         # synchronisation both queues start together and the launches need ~10 steps to settle into the staggered rhythm in
-        # which one launch's drain is filled by the other queue (tools/region_edge_probe.py: T = ~60 us + K x steady).
+        # which one launch's drain is filled by the other queue (tools/labs/region_edge_probe.py: T = ~60 us + K x steady).
         respin()
         k_long = 10 * K
         torch.cuda.synchronize()

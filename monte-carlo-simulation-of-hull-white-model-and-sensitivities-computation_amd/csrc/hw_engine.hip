@@ -270,10 +270,10 @@ Geometry geometry(const hw_ctx* c, int64_t n_units, int ilp, bool wide_rows = fa
 
 // Pairs (paths) in flight per thread of the superposed ZBC / Vega kernels.  Two -- their Philox blocks interleaved
 // (philox_block_prio_x2) -- halve the number of waves and with it the per-wave work outside the time loop (key setup,
-// payoff epilogue, the five DPP reductions in double: ~700 issue cycles a wave).  Measured (tools/ilp_probe.py, one launch
+// payoff epilogue, the five DPP reductions in double: ~700 issue cycles a wave).  Measured (tools/labs/ilp_probe.py, one launch
 // at a time): +1.0 % at 2^22 pairs and +1.2 % at 2^26 on the 1000-step grid (500 executed steps), nothing at 2000 executed
 // steps (42.69 vs 42.63 ms at 2^26 pairs: the per-wave overhead is four times smaller there).  Where the rule starts was
-// re-measured in the loop bench.py times (tools/ilp_pipeline_probe.py, K = 20 calls, two queues / one queue): 2^20 pairs
+// re-measured in the loop bench.py times (tools/labs/ilp_pipeline_probe.py, K = 20 calls, two queues / one queue): 2^20 pairs
 // +1.9 % / +0.4 %, 2^21 +1.4 % / +1.0 %, 2^19 +1.1 % / -0.9 %, 2^18 -3 % / -9 % (half a chip-fill of waves).  So: two from
 // TWO chip-fills of pairs up (2^20 on 256 CUs: one full round of 8 waves per SIMD) when the path has at most 1024 steps, in the
 // float (y, W) loop; one for the double engine, the multi-scenario kernel and the per-step fallback under weak mean

@@ -171,7 +171,7 @@ __device__ __forceinline__ void normal4(const PhiloxKey& k, const PhiloxPath& pp
 }
 
 // ------------------------------------------------------------------------------------------
-// Issue-priority choreography of the hot loop (measured on MI355X, tools/loop_lab.hip family L5:
+// Issue-priority choreography of the hot loop (measured on MI355X, tools/labs/loop_lab.hip family L5:
 // 312 -> 272 cycles per Philox block).  A gfx950 SIMD issues single-rate VALU ops of two waves side by
 // side, but v_mad_u64_u32, v_cvt and the transcendentals run alone.  With all waves at equal priority
 // the exclusive ops of one wave keep splitting the pairs of the others; raising the wave's priority
@@ -272,7 +272,7 @@ __device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const Phil
 // Block j of TWO paths of one thread in lockstep (pairs in flight = 2): the four multiplies of a round back to back at
 // priority 1, the four key mixes at priority 0 -- two independent dependency chains per wave and half as many priority
 // toggles per pair.  Same words as two philox_block_prio<UHI> calls.  What it buys is half as many waves, i.e. half the
-// per-wave work outside the loop: +1.0 % at 2^22 pairs, +1.2 % at 2^26 with 500 steps per path (tools/ilp_probe.py; see
+// per-wave work outside the loop: +1.0 % at 2^22 pairs, +1.2 % at 2^26 with 500 steps per path (tools/labs/ilp_probe.py; see
 // effective_ilp() in hw_engine.hip for when the engine uses it).  Needs -fno-slp-vectorize: left alone, the compiler packs the
 // two pairs' step arithmetic into v_pk_* instructions and pays 12 v_mov per block to build their operands (-5 %).
 template <bool UHI>
@@ -389,7 +389,7 @@ __device__ __forceinline__ void normal4_prio(const PhiloxKey& k, const PhiloxPat
 __device__ __forceinline__ float  hw_exp2(float x)  { return __builtin_amdgcn_exp2f(x); }
 // exp2 of a double through the float unit: 2^x = 2^xf (1 + ln2 (x - xf)) with xf = x rounded to float (|x - xf| <=
 // 2^-25 |x|: the first-order term is exact to 1e-15).  The result carries v_exp_f32's own error (measured against libm
-// over 4 M arguments, tools/exp2_probe.py: max 8.4e-8 relative, sd 2.6e-8, mean signed error -2.3e-9) -- the double engine consumes float normals from the same hardware units (|error| <= 2e-5
+// over 4 M arguments, tools/labs/exp2_probe.py: max 8.4e-8 relative, sd 2.6e-8, mean signed error -2.3e-9) -- the double engine consumes float normals from the same hardware units (|error| <= 2e-5
 // absolute on a normal), so a correctly rounded double exp2 (ocml: ~200 issue cycles a call,
 // measured as +5.6 % on the three-scenario kernel at 2^20 pairs) would buy nothing.  |x| < 126 on this path (x ~ O(1)).
 __device__ __forceinline__ double hw_exp2(double x)
@@ -485,7 +485,7 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
 
 // The same for a double: both halves travel through the DPP network (2 v_mov_b32_dpp + 1 v_add_f64 per step;
 // the ds_bpermute form of __shfl_down costs two LDS-crossbar round trips of ~100 cycles per step, and the five
-// sums of the ZBC epilogue made 60 of them per wave: tools/fixed_cost_probe.py).
+// sums of the ZBC epilogue made 60 of them per wave: tools/labs/fixed_cost_probe.py).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_mov(double v)
 {
@@ -863,7 +863,7 @@ __device__ __forceinline__ void ou_walk(const PhiloxKey& key, const PhiloxPath (
     for (int q = 0; q < ILP; q++) uhi = philox_uniform_hi(pp[q], a2s[q]) && uhi;
     HWK_SETPRIO(1);
     // The (y, W) form divides by 1 - e, which amplifies the rounding of W - e y by ~ 1 / ((1 - e) sqrt(n_steps)).
-    // Measured against the double oracle (tools/weak_reversion_probe.py): no excess over the per-step form at
+    // Measured against the double oracle (tools/labs/weak_reversion_probe.py): no excess over the per-step form at
     // (1 - e) sqrt(n) = 0.11 (a = 0.5), 1e-5 of excess at 0.022 (a = 0.1).  It is used from 0.05 up -- every
     // reference configuration: 0.22 at 1000 steps, 0.11 at 4000 -- weak mean reversion or very fine grids fall back
     // to the per-step form.

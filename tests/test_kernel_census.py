@@ -181,7 +181,7 @@ def test_other_kernels_have_no_scratch_and_full_occupancy(listing):
     _, meta = _kernel(listing, "zbc_superposed_kernelIfLi3ELi1E")      # 15 double accumulators: 7 waves per SIMD
     assert meta["ScratchSize"] == 0 and meta["Occupancy"] >= 7, meta
     # four pairs per thread carry 4 x (4 Philox words + y + W + live): 74 registers, 6 waves per SIMD -- measured
-    # faster than two pairs at 8 waves all the same (tools/curve_p_probe.py); it must not spill or drop further
+    # faster than two pairs at 8 waves all the same (tools/labs/curve_p_probe.py); it must not spill or drop further
     _, meta = _kernel(listing, "zcb_curve_blocked_kernelILi4EfE")
     assert meta["ScratchSize"] == 0 and meta["Occupancy"] >= 6 and meta["NumVgprs"] <= 80, meta
     # the double engine: state in double costs registers (y, W take two each) but no occupancy class
