@@ -327,3 +327,25 @@ def test_second_restatement_of_the_vega_body_in_numpy(oracle_mod, hwmc_mod):
     got = float(np.sum((term1 - term2).astype(np.float64)))
     assert got == pytest.approx(o.vega_pathwise(P, fw, n, seed), rel=3e-6)
     assert 0.1 < got / n < 0.4                                           # a Vega near 0.23 on 160 paths
+
+
+def test_vega_terms_scale_is_consistent_with_the_vega_sum(oracle_mod, hwmc_mod):
+    """ora_vega_pathwise_terms (round 4: the scale of the Vega sum's signed terms, used by the GPU parity bounds) runs the
+    SAME per-path body as ora_vega_pathwise: its first output is that sum bit for bit (golden fixture included), the two
+    absolute sums bound it, float and double agree, and shards add up."""
+    p = hwmc_mod.default_params("head")
+    P, f = hwmc_mod.analytic_curve(p)
+    for prec, tol in (("f32", 2e-5), ("f64", 1e-12)):
+        o = oracle_mod.Oracle("head", precision=prec)
+        for n, seed, off in ((1024, 1234, 0), (1000, 777, 123456789012)):
+            s, a1, a2 = o.vega_pathwise_terms(P, f, n, seed, path_offset=off)
+            assert s == o.vega_pathwise(P, f, n, seed, path_offset=off)
+            assert a1 > 0 and a2 > 0 and abs(s) <= (a1 + a2) * (1 + 1e-12)
+            h = n // 2
+            parts = [o.vega_pathwise_terms(P, f, h, seed, path_offset=off), o.vega_pathwise_terms(P, f, n - h, seed, path_offset=off + h)]
+            for k in range(3):
+                assert parts[0][k] + parts[1][k] == pytest.approx((s, a1, a2)[k], rel=1e-12)
+            assert o.vega_pathwise_terms(P, f, n, seed, path_offset=off, n_threads=1) == pytest.approx((s, a1, a2), rel=1e-13)
+    s32 = oracle_mod.Oracle("head", precision="f32").vega_pathwise_terms(P, f, 4096, 99)
+    s64 = oracle_mod.Oracle("head", precision="f64").vega_pathwise_terms(P, f, 4096, 99)
+    assert s32 == pytest.approx(s64, rel=2e-5)
