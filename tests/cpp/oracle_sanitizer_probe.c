@@ -75,6 +75,12 @@ int main(void)
     if (ora_zcb_curve_f64(&m, m.sigma, dd, 1, 4u, 0u, c64, 1)) return 9;
     if (ora_vega_pathwise_f32(&m, m.sigma, df, sdf, P, f, 1000, 5u, 0u, 5.0, 10.0, K, v32, 3)) return 10;
     if (ora_vega_pathwise_f64(&m, m.sigma, dd, sdd, P, f, 65, 6u, 9u, 5.0, 10.0, K, v64, 1)) return 11;
+    {   /* the same body with the scale of its signed terms beside the sum */
+        double t32[3], t64[3];
+        if (ora_vega_pathwise_terms_f32(&m, m.sigma, df, sdf, P, f, 1000, 5u, 0u, 5.0, 10.0, K, t32, 3)) return 20;
+        if (ora_vega_pathwise_terms_f64(&m, m.sigma, dd, sdd, P, f, 65, 6u, 9u, 5.0, 10.0, K, t64, 1)) return 21;
+        if (t32[0] != v32[0] || t64[0] != v64[0] || !(t32[1] > 0.0) || !(t64[2] > 0.0)) return 22;
+    }
 
     float* Pa = malloc(sizeof(float) * nm);
     float* fa = malloc(sizeof(float) * nm);
