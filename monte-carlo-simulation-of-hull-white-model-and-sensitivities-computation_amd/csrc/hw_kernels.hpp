@@ -796,19 +796,28 @@ __global__ void finalize_columns_kernel(const double* __restrict__ partials, int
                                         double* __restrict__ out, int ncol,
                                         unsigned long long* __restrict__ stamps = nullptr, unsigned long long seq = 0)
 {
-    __shared__ double smem[256];
+    __shared__ double smem[4];
     const int k = blockIdx.x % ncol, group = blockIdx.x / ncol;
     const size_t row0 = (size_t)group * nrows;
-    double t = 0.0;
-    for (int b = threadIdx.x; b < nrows; b += blockDim.x) t += partials[(row0 + b) * row_stride + (size_t)k * col_stride];
-    smem[threadIdx.x] = t;
-    __syncthreads();
-    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
-        if (threadIdx.x < s) smem[threadIdx.x] += smem[threadIdx.x + s];
-        __syncthreads();
+    // four rows per trip with independent loads and accumulators (the 1024 rows of a 2^20-pair launch: ONE trip), fixed order
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const int T = blockDim.x;
+    for (int b = threadIdx.x; b < nrows; b += 4 * T) {
+        const double* q = partials + (row0 + b) * row_stride + (size_t)k * col_stride;
+        const size_t step = (size_t)T * row_stride;
+        a0 += q[0];
+        if (b + T < nrows) a1 += q[step];
+        if (b + 2 * T < nrows) a2 += q[2 * step];
+        if (b + 3 * T < nrows) a3 += q[3 * step];
     }
+    double t = (a0 + a1) + (a2 + a3);
+    // 256 threads = 4 waves: a DPP tree per wave (no LDS, no barrier), then ONE barrier and a fixed-order sum of the four
+    // wave totals (round 4; rounds 1-3 ran an LDS tree of eight barriers: ~1 us of a 4 us kernel that every synchronous call waits for)
+    t = wave_sum_to_lane63(t);
+    if ((threadIdx.x & (kWave - 1)) == kWave - 1) smem[threadIdx.x >> 6] = t;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        double r = smem[0];
+        double r = (smem[0] + smem[1]) + (smem[2] + smem[3]);
         if (scale) r *= scale[k];
         if (k == 0 && fix0 >= 0.0) r = fix0;
         out[(size_t)group * ncol + k] = r;
