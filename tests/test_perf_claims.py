@@ -87,7 +87,7 @@ def test_the_readme_table_is_the_committed_bench_line():
             assert 0.99 * lo <= v <= 1.01 * hi, "README row %r says %g-%g for %s, the committed line has %.1f" % (label, lo, hi, key, v)
         if xs is not None:
             v = _lookup(d, keys[0])
-            assert xs == pytest.approx(v / published.get(keys[0], 1064.0), abs=0.1), (label, xs, v)
+            assert xs == pytest.approx(v / published.get(keys[0], 1064.0), rel=0.015), (label, xs, v)   # (the boxes differ by ~1 %)
     # the configs the table does not list as rates
     assert d["cpu_baseline"]["q1_curve"]["value"] > 0 and d["cpu_baseline"]["q1_curve"]["cores"] >= 1          # configs[0]
     ref = d["strong_scaling_reference"]                                                                        # configs[3] on one GPU
