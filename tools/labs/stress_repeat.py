@@ -1,6 +1,13 @@
-import sys, numpy as np
-sys.path.insert(0, '.')
-import hwmc
+#!/usr/bin/env python3
+"""The four stress launches (2^26 pairs x 4000-step grid; ZBC stepper and curve kernel, float and double), six times each:
+ms, launch-average in-kernel clock, cycles per pair-block -- run-to-run scatter of the figures bench.py's `stress` reports."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import hwmc  # noqa: E402
 for prec in ("f32", "f64"):
     p = hwmc.default_params("head", n_steps=4000, precision=prec)
     with hwmc.HullWhiteEngine(p, device=0) as e:
