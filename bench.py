@@ -294,6 +294,11 @@ def main():
         except Exception as exc:                       # a torch without gloo, an interface gloo cannot bind: the side measurement is skipped
             print("bench.py: no host-side group (%s); multi_gpu.single_call_host_sum_ms will be null" % exc, file=sys.stderr)
             host_group = None
+        # every rank must take the same branch later (the side measurement holds collectives): agree on it over the main group
+        ok = torch.tensor([1.0 if host_group is not None else 0.0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) < 1.0:
+            host_group = None
 
     import numpy as np
     import hwmc
