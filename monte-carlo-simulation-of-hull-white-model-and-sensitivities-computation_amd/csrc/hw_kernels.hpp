@@ -796,7 +796,7 @@ __global__ void finalize_columns_kernel(const double* __restrict__ partials, int
                                         double* __restrict__ out, int ncol,
                                         unsigned long long* __restrict__ stamps = nullptr, unsigned long long seq = 0)
 {
-    __shared__ double smem[4];
+    __shared__ double smem[kMaxWaves];
     const int k = blockIdx.x % ncol, group = blockIdx.x / ncol;
     const size_t row0 = (size_t)group * nrows;
     // four rows per trip with independent loads and accumulators (the 1024 rows of a 2^20-pair launch: ONE trip), fixed order
@@ -817,7 +817,8 @@ __global__ void finalize_columns_kernel(const double* __restrict__ partials, int
     if ((threadIdx.x & (kWave - 1)) == kWave - 1) smem[threadIdx.x >> 6] = t;
     __syncthreads();
     if (threadIdx.x == 0) {
-        double r = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+        double r = 0.0;
+        for (int w = 0; w < (int)(blockDim.x + kWave - 1) / kWave; w++) r += smem[w];      // (the engine launches 256 threads: four waves)
         if (scale) r *= scale[k];
         if (k == 0 && fix0 >= 0.0) r = fix0;
         out[(size_t)group * ncol + k] = r;
