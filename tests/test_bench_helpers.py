@@ -93,3 +93,16 @@ def test_tools_and_labs_compile():
     assert len(files) > 30
     for f in files:
         py_compile.compile(f, doraise=True)
+
+
+def test_roofline_report_reads_the_committed_line():
+    """tools/roofline_report.py turns the committed bench line into the table DESIGN.md section 4 quotes: one row per measured
+    launch with its HBM fraction and its achieved / bound cycles; every fraction it prints is within (0, 1.03]."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "roofline_report.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = [l for l in r.stdout.splitlines() if l.startswith(("ZBC", "pathwise", "FD Vega", "curve", "stress"))]
+    assert len(rows) >= 12
+    for l in rows:
+        frac = float(l.split()[-2])
+        assert 0.8 < frac <= 1.03, l
+    assert "curve_f32_p1" in r.stdout and "zbc_f64" in r.stdout and "CPU baseline" in r.stdout
