@@ -39,6 +39,15 @@ time of a synchronous hw_zbc_moments call), `stress` (BASELINE configs[4] on one
 engine, ZBC stepper and curve kernel, each with its HBM and VALU fraction), `strong_scaling_reference`;
 `cpu_baseline` = the oracle on the host cores (the only use of oracle/ here).
 
+Self-verifying line.  Every timed side launch also checks what it computed (`checks`: the price / Vega / curve it returned
+against the Hull-White closed forms within 4 standard errors, float against double to 1e-5, bit-identity where two routes must
+give the same sums, the committed one-GPU constants of <package>/reference_sums.json to 1e-13) and the line ends with `claims`:
+every rate README.md's table quotes, with its ms and its HBM / VALU fractions, in <= 1.5 KB -- the LAST key, so that a record
+which keeps only the tail of this (16 KB) line still carries all of them.  A failed check: the line is printed, exit code 3.
+For N > 1 the last key is `multi_gpu`, ending in `self_check` (hwmc.parallel.self_check): ranks seen == --gpus, sums_step0
+equal to the committed one-GPU sums of the configuration (else exit code 3), strong scaling against the committed one-GPU
+time and against the prediction of DESIGN.md section 6.
+
 VALU bound.  `valu.bound_cycles_per_block` is MEASURED, not modelled: tools/mix_bound.hip times each production loop's own
 instruction stream with its data dependencies removed (tools/gen_mix_bound.py) in shader-clock cycles: the rate at which a
 SIMD issues that instruction mix in the production ORDER when nothing waits for a result.  It is the fastest of the orderings
@@ -157,26 +166,121 @@ def cpu_baseline(P, f, profile, grid_steps, seconds):
     return out
 
 
-def newest_pmc_summary(config_is_default):
-    """HBM traffic per launch from the newest committed rocprofv3 --pmc summary (profiles/rNN_pmc_summary.json), or None:
-    the counters are collected by separate profiler runs of this command (tools/profile_round.sh), never in-process."""
-    if not config_is_default:
-        return None, None
-    best = None
+def pmc_traffic(config_is_default):
+    """roofline.traffic: HBM bytes per launch from the PMC counters -- ONLY when they were measured on this box: the profiler passes
+    run as separate processes (tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, never in-process)
+    and hand their summary over through HWMC_BENCH_PMC_FILE.  Without it traffic is null and traffic_source names the newest
+    committed summary (another box's number: a reference for the reader, not evidence of this run)."""
+    committed = None
     for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")):
         m = re.match(r"r(\d+)_pmc_summary\.json$", os.path.basename(f))
-        if m and (best is None or int(m.group(1)) > best[0]):
-            best = (int(m.group(1)), f)
-    if best is None:
-        return None, None
+        if m and (committed is None or int(m.group(1)) > committed[0]):
+            committed = (int(m.group(1)), f)
+    src = {"measured_in_this_run": False,
+           "committed_reference": ("profiles/" + os.path.basename(committed[1])) if committed else None,
+           "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (separate runs); FETCH_SIZE x2 on gfx950; "
+                  "set HWMC_BENCH_PMC_FILE to a summary taken on this box (tools/profile_round.sh does)"}
+    if committed:
+        try:
+            with open(committed[1]) as fh:
+                src["committed_reference_bytes_per_launch"] = json.load(fh)["hbm_traffic_bytes_per_launch"]["corrected_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
+    path = os.environ.get("HWMC_BENCH_PMC_FILE")
+    if not path or not config_is_default:
+        return None, src
     try:
-        with open(best[1]) as fh:
+        with open(path) as fh:
             d = json.load(fh)
-        return d["hbm_traffic_bytes_per_launch"]["corrected_bytes"], {
-            "file": "profiles/" + os.path.basename(best[1]), "kernel": d.get("kernel"), "command": d.get("command"),
-            "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (separate runs); FETCH_SIZE x2 on gfx950"}
-    except (OSError, KeyError, ValueError):
-        return None, None
+        src.update(measured_in_this_run=True, file=path, kernel=d.get("kernel"), command=d.get("command"))
+        return d["hbm_traffic_bytes_per_launch"]["corrected_bytes"], src
+    except (OSError, KeyError, ValueError) as exc:
+        src["error"] = "HWMC_BENCH_PMC_FILE unreadable: %s" % exc
+        return None, src
+
+
+class Checks:
+    """The line's own correctness checks: every timed side launch looks at what it computed."""
+
+    def __init__(self):
+        self.passed, self.failed = [], []
+
+    def add(self, name, ok, detail=None):
+        (self.passed if ok else self.failed).append(name if ok or detail is None else "%s: %s" % (name, detail))
+        return ok
+
+    def within_se(self, name, got, want, se, n_se=4.0, slack=0.0):
+        """|got - want| <= n_se standard errors (+ slack for float32 storage / discretisation)"""
+        z = abs(got - want) / max(se, 1e-300)
+        return self.add(name, abs(got - want) <= n_se * se + slack, "%.8g vs %.8g = %.2f SE" % (got, want, z))
+
+    def rel(self, name, a, b, tol):
+        import numpy as np
+        a, b = np.asarray(a, float), np.asarray(b, float)
+        worst = float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))) if a.shape == b.shape and a.size else float("inf")
+        return self.add(name, worst <= tol, "max rel diff %.3e > %.1e" % (worst, tol))
+
+    def equal(self, name, a, b):
+        import numpy as np
+        return self.add(name, np.array_equal(np.asarray(a), np.asarray(b)), "not bit-identical")
+
+
+def build_claims(line, passed, failed):
+    """The compact block that ends the N = 1 line (<= 1.5 KB as JSON): every rate README.md's table quotes -- value in M paths/s,
+    ms per call or launch, share of the measured VALU-issue roof --, the size table and the stress launches with their HBM
+    fractions (north_star: 'as fraction of the HBM roofline'), the two vs_baseline countings and the outcome of the line's own
+    checks.  Built from the finished line alone, so tests/test_bench_helpers.py can rebuild it from a committed line."""
+    def dig(d, *ks):
+        for k in ks:
+            d = d.get(k) if isinstance(d, dict) else None
+        return d
+    v = line.get("valu") or {}
+    kiso = dig(line, "roofline", "kernel_ms_avg")
+    cyc_per_ms = (v.get("achieved_cycles_per_block_isolated_launch") or 0.0) / kiso if kiso else None   # of a launch of this step's size
+    bound = v.get("bound_cycles_per_block")
+    vf = lambda ms: (bound / (ms * cyc_per_ms)) if (bound and cyc_per_ms and ms) else None
+    rate = lambda val, ms, fr: [sig(val, 6), sig(ms), sig(fr, 4)]
+    rates = {"kernel_alone": rate(line.get("kernel_Mpaths_per_sec_isolated_launch"), kiso, v.get("frac")),
+             "serial": rate(dig(line, "serial", "value"), dig(line, "serial", "ms_per_step"), vf(dig(line, "serial", "ms_per_step"))),
+             "two_queues": rate(line.get("value"), line.get("ms_per_step"), v.get("frac_timed_region"))}
+    if "sync_call" in line:
+        rates["sync_call"] = rate(line["sync_call"]["value"], line["sync_call"]["ms_per_call"], vf(line["sync_call"]["ms_per_call"]))
+    for k in ("library_pipeline", "long_region"):
+        if k in line:
+            rates[k] = rate(line[k]["value"], line[k]["ms_per_step"], vf(line[k]["ms_per_step"]))
+    if "runs20_single_launch" in line:
+        r20 = line["runs20_single_launch"]
+        rates["runs20_single_launch"] = rate(r20["value"], r20["ms"], vf(r20["ms"] / r20["n_runs"]))
+    if "other_stepper" in line:
+        rates["other_stepper"] = rate(line["other_stepper"]["value"], line["other_stepper"]["ms_per_step"], None)   # (its loop has no twin)
+    for k in ("q1_curve_gpu", "q3_vega_gpu", "q3_fd_vega_gpu"):
+        if k in line:
+            rates[k] = rate(line[k]["value"], line[k]["kernel_ms"], dig(line[k], "valu", "frac"))
+    claims = {"unit": "M paths/s | ms per call or launch | share of the measured VALU-issue roof",
+              "rates_cols": ["value", "ms", "valu_frac"], "rates": rates}
+    if "size_table" in line:
+        claims["size_cols"] = ["pairs_log2", "value", "hbm_frac", "valu_frac"]
+        claims["size_table"] = [[r["pairs_log2"], sig(r["value"], 6), sig(r.get("hbm_frac"), 3), sig(r.get("valu_frac"), 4)]
+                                for r in line["size_table"]["rows"]]
+    if "stress" in line:
+        claims["stress_cols"] = ["ms", "value", "hbm_frac", "valu_frac"]
+        claims["stress"] = {p: {k: [sig(line["stress"][p][k]["kernel_ms"]), sig(line["stress"][p][k]["value"], 6),
+                                    sig(dig(line["stress"][p][k], "hbm", "frac"), 3), sig(dig(line["stress"][p][k], "valu", "frac"), 4)]
+                                for k in ("zbc", "curve")} for p in ("f32", "f64")}
+    claims.update(hbm_frac=sig(dig(line, "roofline", "frac"), 3), vs_baseline=line.get("vs_baseline"),
+                  vs_baseline_counting=dig(line, "config", "counting"), vs_baseline_like_for_like=line.get("vs_baseline_like_for_like"),
+                  checks_passed=len(passed), checks_failed=list(failed))
+    return claims
+
+
+def sig(x, digits=5):
+    """x rounded to `digits` significant digits (None stays None): keeps `claims` short"""
+    if x is None:
+        return None
+    x = float(x)
+    if x == 0.0 or not math.isfinite(x):
+        return x
+    return round(x, digits - 1 - int(math.floor(math.log10(abs(x)))))
 
 
 def mix_bound(live=True):
@@ -242,6 +346,7 @@ def main():
     import faulthandler
     faulthandler.dump_traceback_later(900, exit=True)  # a default run takes well under a minute: never sit in a hang
     rank0 = int(os.environ.get("RANK", "0")) == 0
+    exit_code = 0
     # the measured VALU issue bound (a child process on the GPU: before this process initialises HIP; rank 0, N = 1 only)
     bound = mix_bound(live=rank0 and a.gpus == 1) if rank0 else None
     import torch                                       # first: libhw_hip.so then shares torch's HIP runtime
@@ -484,6 +589,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_regions = [float(x) for x in t.cpu()]
     elapsed = float(np.median(elapsed_regions))
+    chk = Checks()                                         # the line's own correctness checks (rank 0 reports them)
+    exact_price, exact_vega = hwmc.closed_form_zbc(p, P), hwmc.closed_form_vega(p, P)   # Jamshidian on the market curve; d/dsigma
+    se_of = lambda r_: r_["ci95_halfwidth"] / 1.96         # standard error of one control-variate price
+
+    def check_price(name, sums5, n_pairs, P_=P, exact=None, slack=0.0):
+        r_ = hwmc.cv_price(sums5, 2 * n_pairs, float(P_[-1]))
+        chk.within_se(name, r_["price"], exact_price if exact is None else exact, se_of(r_), slack=slack)
+        return r_
 
     # ---- untimed side measurements ---------------------------------------------------------------------------------
     scratch = torch.zeros((max(K, 8), 5), dtype=torch.float64, device=dev)
@@ -536,7 +649,7 @@ def main():
     serial_ms = float(np.median(serial_regions))
     serial_caller_ms = float(np.median(serial_caller_regions))
     if world == 1:
-        assert np.array_equal(scratch[:K].cpu().numpy(), sums), "the stream count changed the sums"
+        chk.equal("serial: one stream gives the timed region's sums bit for bit", scratch[:K].cpu().numpy(), sums)
     clock_mhz = e.profile_clock_mhz() if a.stepper == "superposed" else None
     geo = e.launch_geometry("zbc" if a.stepper == "superposed" else "zbc_ref", shard_n)
 
@@ -623,6 +736,7 @@ def main():
             enqueue(i, 1234 + 12345 * i, scratch[i % K])
         torch.cuda.synchronize()
         long_ms = (time.perf_counter() - tl) * 1e3 / k_long
+        check_price("long_region: price of its last step on row 0 within 4 SE", scratch[0].cpu().numpy(), shard_n)
         extras["long_region"] = {"steps": k_long, "ms_per_step": long_ms, "value": (2 * shard_n / long_ms) / 1000.0, "unit": "M paths/s",
                                  "note": "untimed side measurement: 10 K steps between two synchronisations instead of K; the difference to "
                                          "`value` is the cost of starting and draining the two-queue pipeline once per K steps"}
@@ -640,7 +754,7 @@ def main():
             for _ in range(R_side):
                 got, ms = pipe.simulate_ZBC_batch(shard_n, seeds, path_offset=offset, return_ms=True)
                 ms_list.append(ms / K)
-            assert np.array_equal(got, sums), "hw_pipe_zbc_moments and the timed region disagree"
+            chk.equal("library_pipeline: hw_pipe_zbc_moments returns the timed region's sums bit for bit", got, sums)
             pm = float(np.median(ms_list))
             extras["library_pipeline"] = {"api": "hw_pipe_zbc_moments", "queues": S, "steps": K, "ms_per_step": pm,
                                           "value": (2 * shard_n / pm) / 1000.0, "unit": "M paths/s", "tuned_ms_per_step": tuned_ms,
@@ -660,6 +774,7 @@ def main():
                 enqueue(i, 1234 + 12345 * i, scratch[i], which=other)
             torch.cuda.synchronize()
             alt_ms = (time.perf_counter() - ta) * 1e3 / K
+            chk.rel("other_stepper: the two steppers agree on the same draws to 1e-5", scratch[:K].cpu().numpy(), sums, 1e-5)
             extras["other_stepper"] = {"stepper": "reference" if other == hwmc.HW_STEPPER_REFERENCE else "superposed",
                                        "ms_per_step": alt_ms, "value": (2 * shard_n / alt_ms) / 1000.0, "unit": "M paths/s"}
         if a.stepper == "superposed":
@@ -668,9 +783,10 @@ def main():
             respin()                                       # (the reference-stepper kernel ran last)
             ms20 = []
             for _ in range(5):
-                _, ms = e.simulate_ZBC_runs(shard_n, 1234, n_runs=20, seed_stride=12345, return_ms=True)
+                rows20, ms = e.simulate_ZBC_runs(shard_n, 1234, n_runs=20, seed_stride=12345, return_ms=True)
                 ms20.append(ms)
             m20 = float(np.median(ms20))
+            chk.equal("runs20_single_launch: per-run sums bit-identical to the separate launches", rows20[:min(K, 20)], sums[:min(K, 20)])
             extras["runs20_single_launch"] = {"n_runs": 20, "pairs_per_run": shard_n, "ms": m20, "value": (20 * 2 * shard_n / m20) / 1000.0,
                                               "unit": "M paths/s", "note": "path kernel + column pass of hw_zbc_moments_runs, hipEvent pair, median of 5"}
         def isolated_ms(eng, fn, reps, pair=True):
@@ -711,9 +827,17 @@ def main():
             for j in range(12):
                 ec.simulate_zcb(1 << 20, 1234 + j)          # back-to-back pair: the second launch is the timed one
                 ec.profile_enable(1)
-                ec.simulate_zcb(1 << 20, 1234 + j)
+                psum = ec.simulate_zcb(1 << 20, 1234 + j)
                 msq.append(float(ec.profile_read(1)[0]))
             mq = float(np.median(msq))
+            Pc, _ = hwmc.analytic_curve(pc)
+
+            def check_curve(name, psum_, n_, pp_, Pex):
+                """path count exact; every P(0,T) within 4 SE (+ float32 storage of the exact curve) of the closed form"""
+                sec = hwmc.curve_standard_errors(pp_, Pex, n_)
+                z = np.abs(psum_[1:] / (2.0 * n_) - np.asarray(Pex, np.float64)[1:]) / (sec[1:] + 5e-8)
+                chk.add(name, bool(psum_[0] == 2.0 * n_ and z.max() <= 4.0), "P_sum[0] = %r, worst maturity %d at %.2f SE" % (psum_[0], int(z.argmax()) + 1, z.max()))
+            check_curve("q1_curve_gpu: path count exact, every P(0,T) within 4 SE of the exact curve", psum, 1 << 20, pc, Pc)
             if os.environ.get("HWMC_BENCH_TRACE"):
                 print("bench: q1 curve launches ms", ["%.4f" % x for x in msq], file=sys.stderr, flush=True)
             extras["q1_curve_gpu"] = {"pairs": 1 << 20, "grid_steps": 1000, "maturities": 100, "kernel_ms": mq,
@@ -732,9 +856,13 @@ def main():
         for j in range(5):
             e.simulate_sensitivity(1 << 20, 4242 + j)       # back-to-back pair: the second launch is the timed one
             e.profile_enable(1)
-            e.simulate_sensitivity(1 << 20, 4242 + j)
+            vsum = e.simulate_sensitivity(1 << 20, 4242 + j)
             msv.append(float(e.profile_read(1)[0]))
         mv = float(np.median(msv))
+        # its standard error from eight batch means of 2^17 paths (one more launch, untimed), then the timed launch's own result
+        bm = e.simulate_sensitivity_runs(1 << 17, 99, n_runs=8) / float(1 << 17)
+        se_vega = float(np.std(bm, ddof=1)) / math.sqrt(8.0)
+        chk.within_se("q3_vega_gpu: pathwise Vega within 4 SE of d(closed form)/d(sigma)", vsum / float(1 << 20), exact_vega, se_vega)
         extras["q3_vega_gpu"] = {"paths": 1 << 20, "grid_steps": a.grid_steps, "kernel_ms": mv, "value": ((1 << 20) / mv) / 1000.0,
                                  "kernel_ms_for_valu": mv,
                                  "unit": "M paths/s", "vs_v100_509": (((1 << 20) / mv) / 1000.0) / V100_PUBLISHED_Q3_MPATHS,
@@ -755,6 +883,8 @@ def main():
             mhz_fd = clock_of(e)
             sc = fd_fn(1234)
             pr = [hwmc.cv_price(x, 2 << 20, float(P[-1]))["price"] for x in sc]
+            check_price("q3_fd_vega_gpu: base-scenario price within 4 SE", sc[0], 1 << 20)
+            chk.within_se("q3_fd_vega_gpu: finite-difference Vega within 4 SE of d(closed form)/d(sigma)", (pr[2] - pr[1]) / (2.0 * eps), exact_vega, se_vega)
             extras["q3_fd_vega_gpu"] = {
                 "pairs": 1 << 20, "scenarios": 3, "epsilon": eps, "kernel_ms": ms_fd,
                 "value": (2 * (1 << 20) / ms_fd) / 1000.0, "unit": "M paths/s (per scenario: all three come from one pass)",
@@ -769,10 +899,14 @@ def main():
             table = []
             for lg in (20, 22, 24, 26):
                 n_ = 1 << lg
-                fn_ = lambda n_=n_: e.simulate_ZBC_control_variate(n_, 11)
+                last_ = {}
+                fn_ = lambda n_=n_: last_.__setitem__("sums", e.simulate_ZBC_control_variate(n_, 11))
                 fn_()
                 ms_ = float(np.median(isolated_ms(e, fn_, 5 if lg < 26 else 3, pair=lg < 24)))
+                check_price("size_table 2^%d: price within 4 SE" % lg, last_["sums"], n_)
+                bytes_ = e.launch_geometry("zbc", n_)["partial_bytes"] + 40
                 row = {"pairs_log2": lg, "kernel_ms": ms_, "value": (2 * n_ / ms_) / 1000.0,
+                       "hbm_frac": bytes_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": bytes_,
                        "valu_frac": valu_of(ms_, n_, steps_s1, clock_of(e), "zbc_" + a.precision)["frac"]}
                 table.append(row)
             extras["size_table"] = {"grid_steps": a.grid_steps, "steps_executed": steps_s1, "unit": "M paths/s", "rows": table,
@@ -795,6 +929,10 @@ def main():
                 tcall.append((time.perf_counter() - tq) * 1e3)
                 assert rc_ == 0
             sc_ms = float(np.median(tcall))
+            if K >= 20 and shard_n == 1 << 20:                # the 20th call priced the 20th timed step's seed
+                chk.equal("sync_call: the last call's sums equal the timed region's for the same seed", np.array(out5[:]), sums[19])
+            else:
+                check_price("sync_call: price of the last call within 4 SE", np.array(out5[:]), 1 << 20)
             extras["sync_call"] = {"api": "hw_zbc_moments(ctx, req, out, NULL)", "pairs": 1 << 20, "calls": 20, "ms_per_call": sc_ms,
                                    "ms_min": float(np.min(tcall)), "value": (2 * (1 << 20) / sc_ms) / 1000.0,
                                    "vs_baseline": (2 * (1 << 20) / sc_ms) / 1000.0 / V100_PUBLISHED_MPATHS, "unit": "M paths/s",
@@ -806,20 +944,32 @@ def main():
                                     "stepper, 4000 for the curve), float32 vs float64 stepper",
                           "pairs": 1 << 26, "grid_steps": 4000, "launches_timed": 3}
                 nS = 1 << 26
+                stress_out = {}
                 for prec in ("f32", "f64"):
                     ps = hwmc.default_params(a.profile, n_steps=4000, precision=prec)
                     with hwmc.HullWhiteEngine(ps, device=local_rank) as es:
                         Ps, fs = hwmc.analytic_curve(ps)
                         es.load_market_data(Ps, fs)
                         ent = {}
+                        exact_s = hwmc.closed_form_zbc(ps, Ps)
                         for kname, fn_, steps_, geo_name in (
                                 ("zbc", lambda: es.simulate_ZBC_control_variate(nS, 1234), 2000, "zbc"),
                                 ("curve", lambda: es.simulate_zcb(nS, 1234), 4000, "zcb_blocked")):
                             fn_()                                                   # one untimed launch (43..100 ms: the clocks settle)
                             es.profile_enable(3)
                             for _ in range(3):
-                                fn_()
+                                res_ = fn_()
                             msl = [float(x) for x in es.profile_read(3)]
+                            stress_out[(prec, kname)] = res_
+                            # the timed launch's own output: closed form within 4 SE, and the committed one-GPU constant (1e-13)
+                            if kname == "zbc":
+                                check_price("stress.%s.zbc: price within 4 SE of the closed form" % prec, res_, nS, P_=Ps, exact=exact_s, slack=2e-6)
+                            else:
+                                check_curve("stress.%s.curve: path count exact, every P(0,T) within 4 SE" % prec, res_, nS, ps, Ps)
+                            key_ = hwmc.parallel.reference_key("zbc" if kname == "zbc" else "zcb", a.profile, prec,
+                                                               "superposed" if kname == "zbc" else "blocked", 4000, 26, 1234)
+                            if key_ in hwmc.parallel.load_reference_sums():
+                                chk.rel("stress.%s.%s: equals the committed one-GPU sums (1e-13)" % (prec, kname), res_, hwmc.parallel.load_reference_sums()[key_], 1e-13)
                             ms_ = float(np.median(msl))
                             mhz_ = clock_of(es)
                             g_ = es.launch_geometry(geo_name, nS)
@@ -832,6 +982,8 @@ def main():
                                           "valu": valu_of(ms_, nS, steps_, mhz_, loop), "launch_geometry": g_}
                         stress[prec] = ent
                 stress["f64_over_f32"] = {k: stress["f64"][k]["kernel_ms"] / stress["f32"][k]["kernel_ms"] for k in ("zbc", "curve")}
+                chk.rel("stress.zbc: float and double stepper agree on the same draws to 1e-5", stress_out[("f32", "zbc")], stress_out[("f64", "zbc")], 1e-5)
+                chk.rel("stress.curve: float and double agree on every maturity to 1e-5", stress_out[("f32", "curve")], stress_out[("f64", "curve")], 1e-5)
                 extras["stress"] = stress
                 respin()
         # strong-scaling reference: the N > 1 workload (2^total_log2 pairs per step) on this ONE GPU, same pipelining
@@ -853,6 +1005,10 @@ def main():
             ref_serial_ms = (time.perf_counter() - tr) * 1e3 / kk
             ref_sums0 = [float(x) for x in scratch[0].cpu().numpy()]           # seed 1234 = the first timed step of an N-GPU run
             ref_kernel_ms = float(np.median(isolated_ms(e, lambda: e.simulate_ZBC_control_variate(nref, 1234), 3, pair=False)))
+            check_price("strong_scaling_reference: price of the 2^%d-pair call within 4 SE" % a.total_log2, ref_sums0, nref)
+            key_ = hwmc.parallel.reference_key("zbc", a.profile, a.precision, a.stepper, a.grid_steps, a.total_log2, 1234)
+            if key_ in hwmc.parallel.load_reference_sums():
+                chk.rel("strong_scaling_reference: equals the committed one-GPU sums (1e-13)", ref_sums0, hwmc.parallel.load_reference_sums()[key_], 1e-13)
             extras["strong_scaling_reference"] = {
                 "pairs_per_step": nref, "n_gpus": 1, "ms_per_step": ref_ms, "value": (2 * nref / ref_ms) / 1000.0,
                 "serial_ms_per_step": ref_serial_ms, "kernel_ms": ref_kernel_ms, "unit": "M paths/s",
@@ -880,7 +1036,14 @@ def main():
         algo_bytes = geo["partial_bytes"] + 5 * 8         # partial rows written + the 5 sums (stateless Philox: no state traffic)
         achieved = algo_bytes / (kiso * 1e-3) / 1e9
         default_cfg = (a.stepper == "superposed" and shard_n == 1 << 20 and a.grid_steps == 1000 and a.precision == "f32" and not a.block)
-        traffic, traffic_src = newest_pmc_summary(default_cfg)
+        traffic, traffic_src = pmc_traffic(default_cfg)
+        # the K timed steps ARE the 20-run validation: their mean price against the closed form, with their own standard error
+        # (the standard error of the mean from the runs' own normal-theory errors: the spread of K = 3 prices would be no estimate)
+        se_mean = math.sqrt(sum(se_of(r_) ** 2 for r_ in prices)) / K
+        chk.within_se("timed region: mean price of the K runs within 4 SE of the closed form", st["mean"], exact_price, se_mean, slack=1e-6)
+        key0 = hwmc.parallel.reference_key("zbc", a.profile, a.precision, a.stepper, a.grid_steps, max(n_total.bit_length() - 1, 0), 1234)
+        if n_total == 1 << max(n_total.bit_length() - 1, 0) and a.scaling == "strong" and key0 in hwmc.parallel.load_reference_sums():
+            chk.rel("timed region: sums of its first step equal the committed one-GPU sums (1e-13)", sums[0], hwmc.parallel.load_reference_sums()[key0], 1e-13)
         vm = VALU_MODEL["superposed_f64" if (a.stepper == "superposed" and a.precision == "f64") else a.stepper]
         cyc_per_block = 2 * vm["full"] + 4 * vm["half"] + 8 * vm["quarter"]
         waves = (shard_n + 63) // 64
@@ -911,14 +1074,21 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": round(value / V100_PUBLISHED_MPATHS, 3),
+            "vs_baseline_counting": ("`value` = K independent pricing calls with %d launches in flight per GPU, over the V100's one launch between two "
+                                     "events (2_option_pricing.cu:131-144); like for like -- this kernel alone on the chip, the same event-pair "
+                                     "timing -- is vs_baseline_like_for_like" % S),
+            "vs_baseline_like_for_like": round((2 * shard_n / kiso) / 1000.0 / V100_PUBLISHED_MPATHS, 3) if world == 1 else None,
             "baseline": {"value": V100_PUBLISHED_MPATHS, "unit": "M paths/s", "hardware": "1x Tesla V100",
                          "source": "reference README.md:44,162 (single un-warmed launch)"},
             "dtype": a.precision, "data": "synthetic",
             "timed_region_s": round(float(sum(elapsed_regions)), 4),
-            "value_spread": {"timed_regions": R, "steps_per_region": K, "min": round(vals[0], 2), "median": round(value, 2),
-                             "max": round(vals[-1], 2), "region_ms": [round(x * 1e3, 4) for x in elapsed_regions],
-                             "note": "`value` is the median region; every region times exactly K steps between barrier + synchronize"},
+            "value_spread": {"timed_regions": R, "steps_per_region": K, "min": round(vals[0], 2), "p10": round(vals[len(vals) // 10], 2),
+                             "median": round(value, 2), "p90": round(vals[(9 * len(vals)) // 10], 2), "max": round(vals[-1], 2),
+                             "region_ms_min_median_max": [round(float(x) * 1e3, 4) for x in (min(elapsed_regions), elapsed, max(elapsed_regions))],
+                             "note": "`value` is the median region; every region times exactly K steps between barrier + synchronize; "
+                                     "HWMC_BENCH_REGIONS_FILE=path writes every region's time there (they left the line in round 5)"},
             "config": {"workload": workload,
+                       "counting": ("%d queues in flight" % S) if S > 1 else "strictly serial",
                        "pairs_per_step": n_total, "pairs_per_gpu": shard_n, "effective_paths": n_eff, "grid_steps": a.grid_steps,
                        "steps_executed": steps_exec, "stepper": a.stepper, "theta_profile": a.profile,
                        "rng": "Philox4x32-10 (rocRAND layout), stateless, subsequence = global pair id",
@@ -950,6 +1120,9 @@ def main():
                                                             "untimed replay of the same alternation, / K; the event pairs themselves cost queue bubbles, so this "
                                                             "replay runs slower than the timed region",
                          "algorithmic_bytes_per_launch": algo_bytes, "launch_geometry": geo,
+                         # the binding roof's own fractions as scalars of this block too (the full account is `valu`)
+                         "valu_issue_bound_cycles_per_block": bcyc, "valu_issue_frac_isolated_launch": (bcyc / achieved_cyc_iso) if bcyc else None,
+                         "valu_issue_frac_timed_region": (bcyc / achieved_cyc) if bcyc else None,
                          "note": "stateless Philox: the path kernel has ~0 algorithmic HBM traffic; the binding roof is VALU issue (see valu)"},
             "valu": {"bound": "valu-issue",
                      "how": "bound = measured dependency-free rate of the production ordering: shader-clock cycles per Philox block per SIMD of the "
@@ -1015,11 +1188,32 @@ def main():
                                  "end_to_end_ms_per_step": ms_per_step}
         if rehearsal:
             line["rehearsal"] = "gloo, all ranks on device 0 -- control-flow check only, not a measurement"
-        assert 0.0 < st["mean"] < 0.1 and all(np.isfinite(s).all() for s in sums), "implausible reduced sums"
+        chk.add("timed region: the reduced sums are finite and the mean price plausible",
+                bool(0.0 < st["mean"] < 0.1 and all(np.isfinite(x).all() for x in sums)), "mean price %r" % st["mean"])
         if os.environ.get("HWMC_BENCH_TRACE"):
             print("bench: GPU legs done", file=sys.stderr, flush=True)
+        if os.environ.get("HWMC_BENCH_REGIONS_FILE"):
+            with open(os.environ["HWMC_BENCH_REGIONS_FILE"], "w") as fh:
+                json.dump({"steps_per_region": K, "region_ms": [round(x * 1e3, 5) for x in elapsed_regions],
+                           "region_ms_hip_events": [round(float(x), 5) for x in region_ms_events]}, fh)
+        line["checks"] = {"passed": len(chk.passed), "failed": len(chk.failed), "failed_names": chk.failed, "passed_names": chk.passed,
+                          "how": "closed forms = Jamshidian's bond-option price on the market curve and its sigma-derivative, the exact "
+                                 "P(0,T); SE = the estimator's own standard error; 1e-13 = float64 summation order only"}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(P, f, a.profile, a.grid_steps, a.cpu_seconds)
+        if dist_on:
+            # LAST key for N > 1: the multi-GPU block, ending in the self-check against the committed one-GPU constants
+            mg = line.pop("multi_gpu")
+            mg["self_check"] = hwmc.parallel.self_check(dict(line, multi_gpu=mg), a.gpus)
+            if world > 1:
+                exit_code = 3 if mg["self_check"]["failed"] else exit_code
+            line["multi_gpu"] = mg
+        else:
+            # LAST key for N = 1: every rate README.md quotes, with its ms and its fractions of the HBM and VALU-issue roofs
+            claims = build_claims(line, chk.passed, chk.failed)
+            line["claims"] = claims
+        if chk.failed:
+            exit_code = 3
         print(json.dumps(line), flush=True)
     for eng in engines:
         eng.close()
@@ -1028,9 +1222,13 @@ def main():
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        print("bench.py: the line above FAILED its own checks (checks.failed_names / multi_gpu.self_check.failed): exit %d" % exit_code, file=sys.stderr)
+    return exit_code
 
 
 if __name__ == "__main__":
-    main()
+    rc = main()
     if os.environ.get("HWMC_BENCH_TRACE"):
         print("bench: main returned", file=sys.stderr, flush=True)
+    sys.exit(rc)

@@ -36,7 +36,8 @@
 extern "C" {
 #endif
 
-#define HW_ABI_VERSION 5   /* 5: diagnostics, profiling hooks and launch knobs moved to hw_mc_diag.h (same symbols, same library) */
+#define HW_ABI_VERSION 6   /* 5: diagnostics, profiling hooks and launch knobs moved to hw_mc_diag.h (same symbols, same library);
+                               6: hw_pipe_queue added to hw_mc_diag.h (additive: nothing in this header changed) */
 
 /* error codes */
 #define HW_OK            0

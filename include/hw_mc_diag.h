@@ -75,6 +75,13 @@ int  hw_profile_clock(hw_ctx* ctx, double* shader_mhz);
  * after the first probe's entry (any output pointer may be NULL); *n_out = how many probed. */
 int  hw_profile_clock_samples(hw_ctx* ctx, double* mhz, double* start_us, double* end_us, int32_t cap, int32_t* n_out);
 
+/* Queue q (0 .. n_queues-1) of a pipe: the context whose workspaces its launches use and the index (0..7) of the candidate
+ * stream the tuning step picked for it; request i of a batch goes to queue i % n_queues.  With hw_profile_enable /
+ * hw_profile_spans on the contexts a test can see that a batch really alternated over distinct streams and that launches of
+ * different queues were in flight together, without a wall clock.  The context stays owned by the pipe (never hw_destroy it).
+ * Any output pointer may be NULL; q out of range -> HW_E_INVALID. */
+int  hw_pipe_queue(hw_pipe* pipe, int32_t q, hw_ctx** ctx_out, int32_t* stream_index_out, int32_t* n_queues_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ HW_TABLES_F64, HW_TABLES_REF_F32 = 0, 1
 HW_STEPPER_SUPERPOSED, HW_STEPPER_REFERENCE = 0, 1
 HW_DRIFT_BASE, HW_DRIFT_SHIFTED = 0, 1
 HW_COMM_RCCL, HW_COMM_HOST_SUM = 0, 1
-ABI_VERSION = 5                 # HW_ABI_VERSION of include/hw_mc.h
+ABI_VERSION = 6                 # HW_ABI_VERSION of include/hw_mc.h
 
 
 class HwParams(C.Structure):
@@ -108,6 +108,7 @@ DIAG_SIGNATURES = {
     "hw_get_launch_geometry": (C.c_int, [_CTX, C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                          C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "hw_get_kernel_info": (C.c_int, [_CTX, C.c_char_p, C.POINTER(HwKernelInfo)]),
+    "hw_pipe_queue": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(_CTX), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 
 _lib = None

@@ -270,7 +270,7 @@ Geometry geometry(const hw_ctx* c, int64_t n_units, int ilp, bool wide_rows = fa
 
 // Pairs (paths) in flight per thread of the superposed ZBC / Vega kernels.  Two -- their Philox blocks interleaved
 // (philox_block_prio_x2) -- halve the number of waves and with it the per-wave work outside the time loop (key setup,
-// payoff epilogue, the five DPP reductions in double: ~700 issue cycles a wave).  Measured (tools/labs/ilp_probe.py, one launch
+// payoff epilogue, the five DPP reductions in double: ~700 issue cycles a wave).  Measured (profiles/r02_ilp_pipeline_probe.txt, one launch
 // at a time): +1.0 % at 2^22 pairs and +1.2 % at 2^26 on the 1000-step grid (500 executed steps), nothing at 2000 executed
 // steps (42.69 vs 42.63 ms at 2^26 pairs: the per-wave overhead is four times smaller there).  Where the rule starts was
 // re-measured in the loop bench.py times (tools/labs/ilp_pipeline_probe.py, K = 20 calls, two queues / one queue): 2^20 pairs
@@ -1471,6 +1471,16 @@ int hw_pipe_set_market(hw_pipe* pp, const float* P, const float* f, int32_t n_ma
         const int rc = hw_set_market(c, P, f, n_mat);
         if (rc) return rc;
     }
+    return HW_OK;
+}
+
+int hw_pipe_queue(hw_pipe* pp, int32_t q, hw_ctx** ctx_out, int32_t* stream_index_out, int32_t* n_queues_out)
+{
+    if (!pp) return fail(HW_E_INVALID, "null pipe");
+    if (q < 0 || q >= (int32_t)pp->ctx.size()) return fail(HW_E_INVALID, "queue %d out of range (the pipe has %zu)", q, pp->ctx.size());
+    if (ctx_out) *ctx_out = pp->ctx[q];
+    if (stream_index_out) *stream_index_out = pp->chosen[q];
+    if (n_queues_out) *n_queues_out = (int32_t)pp->ctx.size();
     return HW_OK;
 }
 

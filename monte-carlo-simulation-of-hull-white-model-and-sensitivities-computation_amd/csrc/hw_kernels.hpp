@@ -272,7 +272,7 @@ __device__ __forceinline__ void philox_block_prio(const PhiloxKey& k, const Phil
 // Block j of TWO paths of one thread in lockstep (pairs in flight = 2): the four multiplies of a round back to back at
 // priority 1, the four key mixes at priority 0 -- two independent dependency chains per wave and half as many priority
 // toggles per pair.  Same words as two philox_block_prio<UHI> calls.  What it buys is half as many waves, i.e. half the
-// per-wave work outside the loop: +1.0 % at 2^22 pairs, +1.2 % at 2^26 with 500 steps per path (tools/labs/ilp_probe.py; see
+// per-wave work outside the loop: +1.0 % at 2^22 pairs, +1.2 % at 2^26 with 500 steps per path (profiles/r02_ilp_pipeline_probe.txt; see
 // effective_ilp() in hw_engine.hip for when the engine uses it).  Needs -fno-slp-vectorize: left alone, the compiler packs the
 // two pairs' step arithmetic into v_pk_* instructions and pays 12 v_mov per block to build their operands (-5 %).
 template <bool UHI>

@@ -58,6 +58,41 @@ def cv_price(sums, n_total, P0S2):
     return out
 
 
+def closed_form_zbc(params, P, S1=5.0, S2=10.0, K=None, sigma=None):
+    """Exact price of the call on P(S1, S2) with strike K under Hull-White (Jamshidian), from the market curve P on the
+    params' maturity grid (S1, S2 on grid points) -- what simulate_ZBC_control_variate (include/common.cuh:286-409) estimates.
+    Its derivative in sigma with the curve held fixed is what both Vega estimators of src/3_sensitivity_analysis.cu target."""
+    a = params.a
+    sig = params.sigma if sigma is None else sigma
+    K = K_DEFAULT if K is None else K
+    step = params.T_final / (params.n_mat - 1)
+    i1, i2 = int(round(S1 / step)), int(round(S2 / step))
+    if abs(i1 * step - S1) > 1e-9 or abs(i2 * step - S2) > 1e-9:
+        raise ValueError("closed_form_zbc: S1, S2 must be maturity grid points")
+    P1, P2 = float(P[i1]), float(P[i2])
+    B = (1.0 - math.exp(-a * (S2 - S1))) / a
+    sp = sig * math.sqrt((1.0 - math.exp(-2.0 * a * S1)) / (2.0 * a)) * B
+    h = math.log(P2 / (K * P1)) / sp + 0.5 * sp
+    cdf = lambda x: 0.5 * (1.0 + math.erf(x / math.sqrt(2.0)))
+    return P2 * cdf(h) - K * P1 * cdf(h - sp)
+
+
+def closed_form_vega(params, P, S1=5.0, S2=10.0, K=None, h=1e-5):
+    s0 = params.sigma
+    return (closed_form_zbc(params, P, S1, S2, K, s0 + h) - closed_form_zbc(params, P, S1, S2, K, s0 - h)) / (2.0 * h)
+
+
+def curve_standard_errors(params, P, n_pairs):
+    """Standard error of the antithetic-pair Monte Carlo estimate of P(0, T_j) (simulate_zcb, include/market_data.cuh:25-79):
+    D = exp(-I) is lognormal with Var I = V(T) = sigma^2/a^2 (T - 2B + (1 - e^{-2aT})/(2a)); the pair mean (D+ + D-)/2 has
+    variance P^2 (cosh V - 1)."""
+    a, s = params.a, params.sigma
+    T = np.linspace(0.0, params.T_final, params.n_mat)
+    B = (1.0 - np.exp(-a * T)) / a
+    V = s * s / (a * a) * (T - 2.0 * B + (1.0 - np.exp(-2.0 * a * T)) / (2.0 * a))
+    return np.asarray(P, np.float64) * np.sqrt(np.maximum(np.cosh(V) - 1.0, 0.0) / n_pairs)
+
+
 def run_statistics(samples):
     """20-run statistics of src/2_option_pricing.cu:305-324 (t = 2.093, df = 19)."""
     x = np.asarray(samples, np.float64)
@@ -392,6 +427,16 @@ class HullWhitePipeline:
             r.S1, r.S2, r.K = float(S1), float(S2), float(K_DEFAULT if K is None else K)
             r.sigma, r.drift_mode, r.stepper = float(sigma), int(drift_mode), int(stepper)
         return reqs
+
+    def queue(self, q):
+        """(context of queue q as a borrowed HullWhiteEngine, index of the candidate stream it uses, number of queues):
+        hw_pipe_queue (include/hw_mc_diag.h).  The borrowed engine is for the profiling hooks only; closing it is a no-op."""
+        ctx, idx, nq = C.c_void_p(), C.c_int32(-1), C.c_int32(0)
+        L.check(self.lib.hw_pipe_queue(self._pipe, int(q), C.byref(ctx), C.byref(idx), C.byref(nq)))
+        eng = HullWhiteEngine.__new__(HullWhiteEngine)
+        eng.lib, eng.params, eng._ctx, eng.P, eng.f = self.lib, self.params, ctx, None, None
+        eng.close = lambda: None                        # owned by the pipe
+        return eng, idx.value, nq.value
 
     def tune(self, n_pairs, seed=1, launches=0, **kw):
         """Pick the streams on this workload (untimed by callers); returns the best time per call in ms."""

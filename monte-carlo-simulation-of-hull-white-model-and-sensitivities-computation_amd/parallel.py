@@ -6,8 +6,14 @@ Because every pair's Philox subsequence is its global id, the union of the shard
 sample set whatever the number of ranks: results differ only by float64 summation order.
 Message sizes: 5 doubles (ZBC), n_mat doubles (curve), 1 double (Vega) -> pure latency on xGMI.
 """
+import json
+import os
+
 import torch
 import torch.distributed as dist
+
+REFERENCE_SUMS_FILE = os.environ.get("HWMC_REFERENCE_SUMS") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_sums.json")
+_reference_cache = None
 
 
 def shard(n_total, rank, world):
@@ -104,6 +110,91 @@ def launch_skew(t_start_wall_s, device="cpu", group=None):
             "how": "max - min over ranks of time.time() when the rank enqueued the first launch of a timed region (same host clock)"}
 
 
+# ---- committed one-GPU constants: an N-GPU line proves itself WITHOUT a companion N = 1 line -----------------------------------
+def reference_key(kernel, profile, precision, stepper, grid_steps, pairs_log2, seed):
+    return "%s|%s|%s|%s|%d|%d|%d" % (kernel, profile, precision, stepper, grid_steps, pairs_log2, seed)
+
+
+def load_reference_sums():
+    """reference_sums.json beside this file (written by tools/make_reference_sums.py on one MI355X): whole-call moment sums
+    per configuration, plus `_one_gpu_ms` (the committed one-GPU times of the same calls) and `_predicted_ms_per_step`."""
+    global _reference_cache
+    if _reference_cache is None:
+        try:
+            with open(REFERENCE_SUMS_FILE) as fh:
+                _reference_cache = json.load(fh)
+        except (OSError, ValueError):
+            _reference_cache = {}
+    return _reference_cache
+
+
+def committed_one_gpu_line(lineN):
+    """The N = 1 side of check_scaling_lines for `lineN`'s configuration, built from the committed constants; None when the
+    store has no entry for it (another size, grid, profile or stepper)."""
+    c = lineN["config"]
+    n = int(c["pairs_per_step"])
+    if n <= 0 or n & (n - 1):
+        return None, None
+    store = load_reference_sums()
+    base = reference_key("zbc", c["theta_profile"], lineN["dtype"], c["stepper"], c["grid_steps"], n.bit_length() - 1, 1234)
+    sums = store.get(base)
+    if sums is None:
+        return None, base
+    t = (store.get("_one_gpu_ms") or {}).get(base.rsplit("|", 1)[0]) or {}
+    ref = {"pairs_per_step": n, "n_gpus": 1, "sums_step0": sums, "ms_per_step": t.get("ms_per_step"),
+           "serial_ms_per_step": t.get("serial_ms_per_step"), "kernel_ms": t.get("kernel_ms"), "source": t.get("source")}
+    line1 = {"metric": lineN["metric"], "unit": lineN["unit"], "dtype": lineN["dtype"], "n_gpus": 1,
+             "config": {k: c[k] for k in ("grid_steps", "steps_executed", "stepper", "theta_profile")},
+             "strong_scaling_reference": ref}
+    return line1, base
+
+
+def self_check(lineN, gpus_requested, rel=1e-13):
+    """What bench.py --gpus N puts into multi_gpu.self_check (rank 0, before it prints): did every requested rank take part,
+    did the N ranks price the sample set ONE GPU prices (sums_step0 against the committed constant of the configuration, 1e-13),
+    and how does ms_per_step compare with the committed one-GPU time and with the prediction written down before any N > 1
+    run existed.  `failed` lists what makes bench.py exit non-zero: a rank count that is not --gpus, or
+    sums that differ.  A configuration without a committed constant (e.g. the 2^18-pair rehearsal) is reported, not failed."""
+    mg = lineN.get("multi_gpu") or {}
+    seen = mg.get("world_size_seen") or {}
+    n = lineN["n_gpus"]
+    out = {"gpus_requested": gpus_requested, "world_size_seen": seen, "failed": []}
+    if not (seen.get("dist") == seen.get("allreduce_of_ones") == n == gpus_requested):
+        out["failed"].append("ranks seen %r, --gpus %d, n_gpus %d" % (seen, gpus_requested, n))
+    line1, key = committed_one_gpu_line(lineN) if lineN.get("scaling") == "strong" else (None, None)
+    out["reference"] = key
+    if line1 is None:
+        out["sums_max_rel_diff"] = None
+        out["verdict"] = "no committed one-GPU constant for this configuration (%s): sample set unchecked" % (key or "weak scaling or odd size")
+        return out
+    a, b = lineN["sums_step0"], line1["strong_scaling_reference"]["sums_step0"]
+    worst = max(abs(x - y) / max(abs(y), 1e-300) for x, y in zip(a, b))
+    out["sums_max_rel_diff"] = worst
+    if worst > rel:
+        out["failed"].append("sums_step0 differ from the committed one-GPU sums by %.3e (relative): another sample set was priced" % worst)
+    ref = line1["strong_scaling_reference"]
+    out["one_gpu_ms_per_step"] = ref["ms_per_step"]
+    out["one_gpu_source"] = ref.get("source")
+    pred = ((load_reference_sums().get("_predicted_ms_per_step") or {}).get(key.rsplit("|", 1)[0]) or {}).get(str(n))
+    if pred:
+        out["predicted_ms_per_step"] = pred
+        out["ms_per_step_over_prediction"] = lineN["ms_per_step"] / pred["throughput_mode"] if pred.get("throughput_mode") else None
+    if n < 2:
+        out["verdict"] = "sample set verified on one rank (the forced-RCCL path of a one-GPU box)" if not out["failed"] else "FAILED: " + "; ".join(out["failed"])
+        return out
+    if out["failed"] or not ref["ms_per_step"]:
+        out["verdict"] = "FAILED: " + "; ".join(out["failed"]) if out["failed"] else "sample set verified; no committed one-GPU time for this configuration"
+        return out
+    try:
+        rep = check_scaling_lines(line1, lineN, rel)
+        out.update(strong_scaling=rep["strong_scaling"], compute_scaling=rep["compute_scaling"], rank_imbalance=rep["rank_imbalance"],
+                   verdict=rep["verdict"])
+    except AssertionError as exc:                     # an invariant beyond ranks and sums (value != paths / time, missing fields)
+        out["failed"].append(str(exc))
+        out["verdict"] = "FAILED: %s" % exc
+    return out
+
+
 def check_scaling_lines(line1, lineN, rel=1e-13):
     """Invariants an N-GPU bench line must satisfy against the N = 1 line of the same build (both are bench.py JSON lines).
     Raises AssertionError naming the violated invariant; returns the scaling report.
@@ -141,7 +232,7 @@ def check_scaling_lines(line1, lineN, rel=1e-13):
     report = {
         "n_gpus": n, "sums_step0_max_rel_diff": worst,
         "strong_scaling": ref["ms_per_step"] / lineN["ms_per_step"],
-        "strong_scaling_serial_reference": ref["serial_ms_per_step"] / lineN["ms_per_step"],
+        "strong_scaling_serial_reference": (ref.get("serial_ms_per_step") or ref["ms_per_step"]) / lineN["ms_per_step"],
         "compute_scaling": (ref.get("kernel_ms") or ref["serial_ms_per_step"]) / slowest,
         "exposed_allreduce_ms_per_step": mg.get("exposed_allreduce_ms_per_step"),
         "launch_skew_median_ms": (mg.get("launch_skew") or {}).get("median_ms"),

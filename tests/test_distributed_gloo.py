@@ -262,3 +262,52 @@ def test_an_n_gpu_line_checks_itself_against_the_n1_line(oracle_mod, hwmc_mod):
     assert par.check_scaling_lines(ref, synth(0.36, 0.355, 0.004))["verdict"].startswith("scales: 7.61x on 8 GPUs")
     assert par.check_scaling_lines(ref, synth(0.45, 0.44, 0.005))["verdict"].startswith("compute-bound shortfall")
     assert par.check_scaling_lines(ref, synth(0.45, 0.355, 0.09))["verdict"].startswith("collective exposed")
+
+
+def test_an_n_gpu_line_proves_itself_against_committed_constants(oracle_mod, hwmc_mod, monkeypatch):
+    """the first N > 1 run on hardware will arrive WITHOUT a companion N = 1 line from the same box, so the
+    one-GPU side of the comparison is committed (reference_sums.json beside hwmc.parallel: whole-call sums per configuration
+    -- deterministic, the driver's box reproduced the builder's to the last bit --, the one-GPU time, the predicted N-GPU
+    times) and bench.py --gpus N puts hwmc.parallel.self_check(line) into multi_gpu.self_check, exiting non-zero when the
+    ranks seen are not --gpus or the sums differ by more than 1e-13.  Here a two-rank line built over gloo (CPU oracle as
+    the compute) goes through it against a store holding the oracle's own whole-call sums."""
+    import copy
+    par = hwmc_mod.parallel
+    p = hwmc_mod.default_params("head")
+    P, f = hwmc_mod.analytic_curve(p)
+    whole = [float(x) for x in oracle_mod.Oracle("head").zbc_moments(P, f, 512, 1234, n_threads=1)]
+    key = par.reference_key("zbc", "head", "f32", "superposed", 1000, 9, 1234)
+    store = {key: whole,
+             "_one_gpu_ms": {key.rsplit("|", 1)[0]: {"ms_per_step": 40.0, "serial_ms_per_step": 41.0, "kernel_ms": 40.0, "source": "test"}},
+             "_predicted_ms_per_step": {key.rsplit("|", 1)[0]: {"2": {"throughput_mode": 20.5, "latency_mode": 21.0}}}}
+    monkeypatch.setattr(par, "_reference_cache", store)
+    lineN = _two_rank_line()
+    sc = par.self_check(lineN, 2)
+    assert sc["failed"] == [] and sc["reference"] == key and sc["sums_max_rel_diff"] <= 1e-13
+    assert sc["world_size_seen"] == {"dist": 2, "allreduce_of_ones": 2} and sc["gpus_requested"] == 2
+    assert sc["one_gpu_ms_per_step"] == 40.0 and sc["strong_scaling"] == pytest.approx(40.0 / lineN["ms_per_step"])
+    assert sc["predicted_ms_per_step"]["throughput_mode"] == 20.5 and sc["ms_per_step_over_prediction"] == pytest.approx(lineN["ms_per_step"] / 20.5)
+    assert sc["verdict"].split(":")[0] in ("scales", "compute-bound shortfall", "collective exposed")
+    # a rank that priced another sample set: caught by the committed sums alone, and named as the reason to exit non-zero
+    bad = par.self_check(_two_rank_line(wrong_seed_rank=1), 2)
+    assert len(bad["failed"]) == 1 and "another sample set" in bad["failed"][0] and bad["verdict"].startswith("FAILED")
+    # fewer ranks than --gpus (a launcher that started 2 of 8), a rank missing from the collective
+    short = par.self_check(lineN, 8)
+    assert any("--gpus 8" in x for x in short["failed"])
+    miss = copy.deepcopy(lineN)
+    miss["multi_gpu"]["world_size_seen"]["allreduce_of_ones"] = 1
+    assert any("ranks seen" in x for x in par.self_check(miss, 2)["failed"])
+    # a configuration without a committed constant is reported, not failed (the 2^18-pair rehearsal, weak scaling)
+    other = copy.deepcopy(lineN)
+    other["config"]["grid_steps"] = 4000
+    sc = par.self_check(other, 2)
+    assert sc["failed"] == [] and sc["sums_max_rel_diff"] is None and "no committed one-GPU constant" in sc["verdict"]
+    # the committed store itself: BASELINE configs[1] and configs[3] are there, with the 2^24-pair call's time and predictions
+    monkeypatch.setattr(par, "_reference_cache", None)
+    real = par.load_reference_sums()
+    k24 = par.reference_key("zbc", "head", "f32", "superposed", 1000, 24, 1234)
+    assert len(real[k24]) == 5 and len(real[par.reference_key("zbc", "head", "f32", "superposed", 1000, 20, 1234)]) == 5
+    assert real["_one_gpu_ms"][k24.rsplit("|", 1)[0]]["ms_per_step"] > 2.0
+    pred = real["_predicted_ms_per_step"][k24.rsplit("|", 1)[0]]
+    assert set(pred) >= {"2", "4", "8"} and pred["8"]["throughput_mode"] < pred["4"]["throughput_mode"] < pred["2"]["throughput_mode"]
+    assert real["_one_gpu_ms"][k24.rsplit("|", 1)[0]]["ms_per_step"] / pred["8"]["throughput_mode"] >= 7.0     # the north star's >= 7x, as predicted

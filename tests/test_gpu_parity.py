@@ -850,6 +850,43 @@ def test_configs_3_and_4_whole_on_one_gpu(setup, hwmc_mod):
     assert abs(r64["price"] - exact) < 4 * r64["ci95_halfwidth"] / 1.96 + 2e-6, (r64["price"], r64["ci95_halfwidth"])   # + trapezoid bias at dt = 0.0025
 
 
+def test_curve_kernel_at_the_stress_size(setup, hwmc_mod):
+    """BASELINE configs[4] for the Q1 kernel: simulate_zcb (include/market_data.cuh:25-79) at 2^26 pairs on the 4000-step grid,
+    float and double engine -- the launch bench.py times as stress.{f32,f64}.curve (8 192 workgroups x 8 passes x two pairs
+    per thread), which no test ran above 2^22 pairs (missing 3).  No oracle finishes this size, so the properties
+    that do not depend on it: the path count is exact (P_sum[0] = 2n); the eight shards of an 8-GPU run add up to the whole
+    (1e-13 double, 1e-9 float: both kernels add rows of 16 lanes in float before they go to double, and a shard of 2^23 pairs
+    is launched as exactly one of the whole launch's eight passes -- same grid, same lanes together --, so only the order of
+    the double additions differs; the float bar would also hold if a later geometry grouped the lanes differently); float and double
+    agree to 1e-5 on every maturity (same draws); every P(0,T) sits within 4 SE of the exact curve (SE 6e-6 at T = 10: a bias
+    of 3e-5 would show); the launch really is the many-pass, two-pairs-per-thread shape."""
+    n, G = 1 << 26, 8
+    e32, _, P4, _ = setup("readme", "f32", 4000)
+    e64, _, _, _ = setup("readme", "f64", 4000)
+    p = e32.params
+    res = {}
+    for name, e, shard_tol in (("f32", e32, 1e-9), ("f64", e64, 1e-13)):
+        g = e.launch_geometry("zcb_blocked", n)
+        assert g["iters"] > 1 and g["units_per_thread"] == 2 and g["grid"] * g["block"] * g["iters"] * 2 >= n, g
+        whole = e.simulate_zcb(n, 1234)
+        assert whole.shape == (p.n_mat,) and whole[0] == 2.0 * n                    # integer path count, exact
+        parts = np.zeros(p.n_mat)
+        for k in range(G):
+            parts = parts + e.simulate_zcb(n // G, 1234, path_offset=k * (n // G))
+        assert parts[0] == 2.0 * n
+        np.testing.assert_allclose(whole[1:], parts[1:], rtol=shard_tol, err_msg=name)
+        assert np.array_equal(whole, e.simulate_zcb(n, 1234))                       # fixed reduction order: bit-reproducible
+        res[name] = whole
+    np.testing.assert_allclose(res["f32"][1:], res["f64"][1:], rtol=REL_F32)
+    se = hwmc_mod.curve_standard_errors(p, P4, n)
+    for name in ("f32", "f64"):
+        Pmc = res[name] / (2.0 * n)
+        z = np.abs(Pmc[1:] - np.asarray(P4, np.float64)[1:]) / (se[1:] + 2e-7)      # + float32 storage of the exact curve
+        assert z.max() < 4.0, (name, int(z.argmax()) + 1, float(z.max()), float(Pmc[-1]), float(P4[-1]))
+        Pq, fq = e32.compute_average_and_forward(res[name], 2 * n)
+        assert Pq[0] == 1.0 and float(Pq[-1]) == pytest.approx(float(P4[-1]), abs=4 * se[-1] + 2e-7)
+
+
 def test_weak_mean_reversion_falls_back_to_the_per_step_form(hwmc_mod, oracle_mod):
     """The float (y, W) form of the time loop divides by 1 - e and is used only while (1 - e) sqrt(steps) >= 0.05
     (ou_walk).  Away from the reference's a = 1 every float32 implementation -- the float32 oracle included -- sits

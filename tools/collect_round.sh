@@ -24,14 +24,19 @@ step "readme pin" 200 python tools/readme_pin_report.py > "$OUT/readme_pin.txt" 
 step "mix bound" 100 tools/bin/mix_bound > "$OUT/mix_bound.txt" 2>&1
 step "mix bound json" 100 tools/bin/mix_bound --json > "$OUT/mix_bound.json" 2>&1
 step "seal cost" 100 python tools/seal_cost_probe.py > "$OUT/seal_cost_probe.txt" 2>&1
-step "clock along the launch" 200 python tools/labs/clock_vs_duration.py > "$OUT/clock_along_the_launch.txt" 2>&1
-step "time-split proxy" 200 python tools/labs/time_split_proxy.py > "$OUT/time_split_proxy.txt" 2>&1
-step "parity envelope" 300 python tools/labs/parity_envelope.py 40 > "$OUT/parity_envelope.txt" 2>&1
+step "reference sums" 100 python tools/make_reference_sums.py --check > "$OUT/reference_sums_check.txt" 2>&1
 step "throughput cpp" 100 ./bin/throughput --theta-profile readme > "$OUT/throughput_cpp.txt" 2>&1
 ( for k in zbc zbc1 zcb1; do timeout -k 5 60 tools/bin/timeline_probe 20 512 $k || exit 1; done ) > "$OUT/timeline_probe.txt" 2>&1 || { echo "timeline failed"; exit 1; }
 step "bench sizes" 600 python tools/bench_sizes.py > "$OUT/bench_size_table.txt" 2>&1
 echo "== rocprofv3 passes"
 timeout -k 10 900 bash tools/profile_round.sh "$TAG" > "$OUT/profile_round.log" 2>&1 || { echo "profile_round failed"; tail -5 "$OUT/profile_round.log"; exit 1; }
+# the PMC passes ran on THIS box: condense them here and hand the summary to the default bench, whose roofline.traffic is then
+# a measurement of this box (without HWMC_BENCH_PMC_FILE bench.py reports traffic = null)
+python tools/summarize_profile.py "gpurun_out/prof_$TAG" "$TAG" > "$OUT/summarize_profile.log" 2>&1 || { echo "summarize failed"; tail -5 "$OUT/summarize_profile.log"; exit 1; }
+mkdir -p "$OUT/profiles" && cp profiles/${TAG}_* "$OUT/profiles/" 2>/dev/null
 echo "== default bench (the driver's command)"
-timeout -k 10 300 python bench.py --steps 20 --warmup 3 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err" || { echo "bench failed"; exit 1; }
+HWMC_BENCH_PMC_FILE="profiles/${TAG}_pmc_summary.json" HWMC_BENCH_REGIONS_FILE="$OUT/bench_n1_regions.json" \
+  timeout -k 10 300 python bench.py --steps 20 --warmup 3 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err" || { echo "bench failed rc=$?"; tail -3 "$OUT/bench_n1.err"; exit 1; }
+tail -c 2048 "$OUT/bench_n1.json" > "$OUT/bench_n1_tail2k.txt"      # what a record that keeps 2 KB of the line holds: must contain "claims"
+grep -q '"claims": {' "$OUT/bench_n1_tail2k.txt" || { echo "the last 2 KB of the line do not hold claims"; exit 1; }
 echo "all steps done"

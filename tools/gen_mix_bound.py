@@ -653,7 +653,7 @@ def generate(search=0):
         variants[name + "_NOPRIO"] = ([x for x in free if not x.startswith(("s_setprio", "s_nop"))], blocks)
         real = [i for i in loop if not i.startswith(("s_cbranch", "s_cmp", "s_branch"))]
         variants["REAL" + name[-1]] = (real, blocks)
-        if name == "PROD1":      # the same loop on priority levels 2/3 instead of 0/1 (tools/labs/pace_lab.hip: rotating priorities)
+        if name == "PROD1":      # the same loop on priority levels 2/3 instead of 0/1 (profiles/r03_pace_lab.txt: rotating priorities)
             variants["REAL1_HI"] = ([re.sub(r"^s_setprio ([01])$", lambda m: "s_setprio %d" % (int(m.group(1)) + 2), x) for x in real], blocks)
     valu = [x for x in variants["PROD1_NOPRIO"][0] if x.startswith("v_")]
     order = {"half": 0, "quarter": 1, "full": 2}

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""From which batch size do two pairs per thread pay?  tools/ilp_probe.py measured one launch at a time; this probe
+"""From which batch size do two pairs per thread pay?  an earlier probe measured one launch at a time; this probe
 measures the loop bench.py times -- K = 20 and K = 200 pricing calls per region alternating over the best stream pair,
 and K = 20 on one queue -- with pairs_in_flight = 1 | 2 forced.  effective_ilp()'s threshold (two chip-fills of pairs)
 comes from here: 2^18 loses, 2^19 is mixed, 2^20 and 2^21 win in both modes.

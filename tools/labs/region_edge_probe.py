@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What do the two EDGES of a timed region cost?  bench.py times K = 20 pricing calls between synchronisations; 200 calls
-in one go run at a lower time per call (tools/priority_probe.py).  This probe separates the candidates:
+in one go run at a lower time per call (profiles/r02_priority_probe.txt).  This probe separates the candidates:
   (1) T(K) for K = 5 ... 400 after a plain synchronise: the fit T = edge + K * steady gives the cost of the edges;
   (2) K = 20 after an idle gap of 0 / 50 us / 200 us / 1 ms / 5 ms / 20 ms (host sleep after the synchronise): does the
       chip lose its clock while it waits for the host?
