@@ -140,6 +140,11 @@ def test_check_scaling_cli_on_driver_shaped_records(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     rep = json.loads(r.stdout.splitlines()[-1])
     assert rep["n_gpus"] == 8 and rep["verdict"].startswith("scales") and rep["strong_scaling"] > 7.0
+    # without an N = 1 line the committed one-GPU constants (reference_sums.json) stand in for it
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_scaling.py"), many], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rep = json.loads(r.stdout.splitlines()[-1])
+    assert rep["n1_side"].startswith("committed constants") and rep["sums_step0_max_rel_diff"] <= 1e-13 and rep["strong_scaling"] > 7.0
     n8["sums_step0"][2] *= 1.0 + 1e-9
     json.dump({"runs": [{"n": 8, "parsed": n8}]}, open(bad, "w"))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_scaling.py"), one, bad], capture_output=True, text=True)
