@@ -204,6 +204,7 @@ class Checks:
 
     def __init__(self):
         self.passed, self.failed = [], []
+        self.z = {}                                        # name -> distance in standard errors, for the statistical checks
 
     def add(self, name, ok, detail=None):
         (self.passed if ok else self.failed).append(name if ok or detail is None else "%s: %s" % (name, detail))
@@ -212,6 +213,7 @@ class Checks:
     def within_se(self, name, got, want, se, n_se=4.0, slack=0.0):
         """|got - want| <= n_se standard errors (+ slack for float32 storage / discretisation)"""
         z = abs(got - want) / max(se, 1e-300)
+        self.z[name.split(":")[0]] = round(z, 2)
         return self.add(name, abs(got - want) <= n_se * se + slack, "%.8g vs %.8g = %.2f SE" % (got, want, z))
 
     def rel(self, name, a, b, tol):
@@ -836,6 +838,7 @@ def main():
                 """path count exact; every P(0,T) within 4 SE (+ float32 storage of the exact curve) of the closed form"""
                 sec = hwmc.curve_standard_errors(pp_, Pex, n_)
                 z = np.abs(psum_[1:] / (2.0 * n_) - np.asarray(Pex, np.float64)[1:]) / (sec[1:] + 5e-8)
+                chk.z[name.split(":")[0]] = round(float(z.max()), 2)
                 chk.add(name, bool(psum_[0] == 2.0 * n_ and z.max() <= 4.0), "P_sum[0] = %r, worst maturity %d at %.2f SE" % (psum_[0], int(z.argmax()) + 1, z.max()))
             check_curve("q1_curve_gpu: path count exact, every P(0,T) within 4 SE of the exact curve", psum, 1 << 20, pc, Pc)
             if os.environ.get("HWMC_BENCH_TRACE"):
@@ -1197,6 +1200,7 @@ def main():
                 json.dump({"steps_per_region": K, "region_ms": [round(x * 1e3, 5) for x in elapsed_regions],
                            "region_ms_hip_events": [round(float(x), 5) for x in region_ms_events]}, fh)
         line["checks"] = {"passed": len(chk.passed), "failed": len(chk.failed), "failed_names": chk.failed, "passed_names": chk.passed,
+                          "distance_in_standard_errors": chk.z,
                           "how": "closed forms = Jamshidian's bond-option price on the market curve and its sigma-derivative, the exact "
                                  "P(0,T); SE = the estimator's own standard error; 1e-13 = float64 summation order only"}
         if world == 1 and not a.no_cpu_baseline:
