@@ -45,6 +45,21 @@ def test_committed_bench_line_carries_the_claims():
         assert d["timed_region_s"] >= 0.5
 
 
+def test_the_tail_of_the_committed_line_holds_the_claims():
+    """VERDICT r4 item 1, 'Done' criterion: a record that keeps only the last 2 KB of the (19 KB) line -- the driver's does --
+    still holds the whole `claims` block: it is the line's last key and at most 1.5 KB."""
+    rnd, d = _newest_bench_line()
+    if rnd < 5:
+        pytest.skip("claims entered the line in round 5")
+    best = os.path.join(ROOT, "profiles", "r%02d_bench_n1.json" % rnd)
+    text = [l for l in open(best).read().splitlines() if l.startswith("{")][-1]
+    tail = text[-2048:]
+    assert '"claims": {' in tail
+    block = json.loads(tail[tail.index('"claims": ') + len('"claims": '):-1])      # from the key to the line's closing brace
+    assert block == d["claims"] and block["checks_failed"] == [] and len(block["rates"]) == 11
+    assert d["checks"]["failed"] == 0 and d["checks"]["passed"] == block["checks_passed"] >= 25
+
+
 def _readme_rows():
     text = open(os.path.join(ROOT, "README.md"), encoding="utf-8").read()
     block = text.split("<!-- perf-table")[1].split("<!-- /perf-table -->")[0]
