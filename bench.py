@@ -68,6 +68,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Multi-process GPU work on this pool needs dmabuf IPC (RCCL's buffer exchange fails with "hipIpcGetMemHandle: invalid argument"
+# under the legacy mode); the variable is read when the HSA runtime starts, i.e. before torch / libhw_hip.so touch the GPU.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # VALU issue model of the path kernel's inner loop, per Philox block = 4 time steps of one pair
 # (instruction counts from the gfx950 disassembly -- tools/loop_census.py, pinned by tests/test_kernel_census.py --,

@@ -718,6 +718,10 @@ int hw_create(const hw_params* p, int device, hw_ctx** out)
     *out = nullptr;
     int rc = validate_params(p);
     if (rc) return rc;
+    // hw_comm_* with RCCL exchanges buffers between the devices' contexts: on hosts whose driver only supports dmabuf IPC the
+    // legacy mode fails with "hipIpcGetMemHandle: invalid argument".  The HSA runtime reads the variable when it starts, so it
+    // is set (never overriding the caller's choice) before the first HIP call a process makes through this library.
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     if (count < 1) return fail(HW_E_HIP, "no HIP device visible");

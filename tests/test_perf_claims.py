@@ -111,7 +111,7 @@ def test_the_readme_table_is_the_committed_bench_line():
     All five BASELINE configs are covered: [0] cpu_baseline.q1_curve + q1_curve_gpu, [1] value, [2] q3_vega_gpu + q3_fd_vega_gpu,
     [3] strong_scaling_reference, [4] stress."""
     rnd, d = _newest_bench_line()
-    assert rnd >= 4, "the README table is round 4's: commit profiles/r04_bench_n1.json"
+    assert rnd >= 5, "the README table is round 5's: commit profiles/r05_bench_n1.json"
     rows = _readme_rows()
     assert len(rows) >= 12
     published = {"claims.rates.q1_curve_gpu": 391.0, "claims.rates.q3_vega_gpu": 509.0}

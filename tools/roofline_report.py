@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The roofline figures of a bench line as one table (no GPU needed):
 
-    python tools/roofline_report.py [profiles/r04_bench_n1.json]
+    python tools/roofline_report.py [profiles/r05_bench_n1.json]
 
 One row per measured launch: time, M paths/s, algorithmic HBM bytes and the fraction of the 8 TB/s HBM roof they amount to,
 achieved shader cycles per Philox pair-block per SIMD (launch time x in-kernel clock x SIMDs / pair-blocks), the measured
