@@ -887,6 +887,39 @@ def test_curve_kernel_at_the_stress_size(setup, hwmc_mod):
         assert Pq[0] == 1.0 and float(Pq[-1]) == pytest.approx(float(P4[-1]), abs=4 * se[-1] + 2e-7)
 
 
+def test_more_than_2_to_the_31_pairs_in_one_call(setup, hwmc_mod):
+    """Maximum sizes: the C ABI counts pairs in int64 and the kernels index them in 64 bits -- one call with 2^31 + 77 pairs
+    (4.3e9 paths: 32 times BASELINE's largest configuration; the grid is capped at 2^20 workgroups and the threads loop) must
+    (i) count its paths exactly -- the curve kernel's P_sum[0] = 2n = 2^32 + 154, not a value wrapped at 32 bits --, (ii) equal
+    the sum of three shard calls that meet at 2^30 and 2^31 (1e-13: same sample set, another order of the double additions),
+    (iii) price the option within 4 SE of the closed form with NO allowance for what a float path and the trapezoid rule may
+    be off by: at 4.3e9 paths SE = 5.5e-7 (1.6e-5 of the price), so a systematic error of the float engine beyond ~2e-6 would
+    show (measured: 1.3e-7 from the closed form, 0.23 SE).  No per-path state exists, so nothing grows with n except time:
+    0.35 s per ZBC call, 0.8 s for the curve."""
+    e, _, P, f = setup("readme")
+    n = (1 << 31) + 77
+    cuts = (0, 1 << 30, 1 << 31, n)
+    whole = e.simulate_ZBC_control_variate(n, 20240613)
+    parts = np.zeros(5)
+    for a, b in zip(cuts, cuts[1:]):
+        parts = parts + e.simulate_ZBC_control_variate(b - a, 20240613, path_offset=a)
+    np.testing.assert_allclose(whole, parts, rtol=1e-13)
+    r = hwmc_mod.cv_price(whole, 2 * n, float(P[-1]))
+    se = r["ci95_halfwidth"] / 1.96
+    assert se < 1e-6 and abs(r["price"] - 0.03544557) < 4 * se, (r["price"], se)
+    assert r["beta"] == pytest.approx(0.166309, abs=1e-4) and r["rho"] == pytest.approx(0.6738, abs=5e-4)   # (measured 0.166324, 0.67340)
+    g = e.launch_geometry("zbc", n)
+    assert g["grid"] <= 1 << 20 and g["iters"] >= 2 and g["grid"] * g["block"] * g["iters"] * g["units_per_thread"] >= n
+    curve = e.simulate_zcb(n, 7)
+    assert curve[0] == 2.0 * n == float((1 << 32) + 154)                               # exact, beyond 32 bits
+    assert abs(curve[-1] / (2.0 * n) - float(P[-1])) < 4 * hwmc_mod.curve_standard_errors(e.params, P, n)[-1] + 2e-6
+    v = e.simulate_sensitivity(n, 11)
+    v_parts = sum(e.simulate_sensitivity(b - a, 11, path_offset=a) for a, b in zip(cuts, cuts[1:]))
+    assert v == pytest.approx(v_parts, rel=1e-12) and v / n == pytest.approx(0.230244, abs=2e-4)
+    print("2^31 + 77 pairs in one call: price %.9f (closed form 0.035445570; SE %.2e), beta* %.6f, rho %.5f, P(0,10) %.8f (exact %.8f), "
+          "pathwise Vega %.6f (closed form 0.230244)" % (r["price"], se, r["beta"], r["rho"], curve[-1] / (2.0 * n), float(P[-1]), v / n))
+
+
 def test_weak_mean_reversion_falls_back_to_the_per_step_form(hwmc_mod, oracle_mod):
     """The float (y, W) form of the time loop divides by 1 - e and is used only while (1 - e) sqrt(steps) >= 0.05
     (ou_walk).  Away from the reference's a = 1 every float32 implementation -- the float32 oracle included -- sits
