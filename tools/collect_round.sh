@@ -26,6 +26,7 @@ step "mix bound json" 100 tools/bin/mix_bound --json > "$OUT/mix_bound.json" 2>&
 step "seal cost" 100 python tools/seal_cost_probe.py > "$OUT/seal_cost_probe.txt" 2>&1
 step "reference sums" 100 python tools/make_reference_sums.py --check > "$OUT/reference_sums_check.txt" 2>&1
 step "shard steps" 300 python tools/shard_steps.py > "$OUT/shard_steps.txt" 2>&1
+step "bias probe" 200 python tools/bias_probe.py > "$OUT/bias_probe.txt" 2>&1
 step "throughput cpp" 100 ./bin/throughput --theta-profile readme > "$OUT/throughput_cpp.txt" 2>&1
 ( for k in zbc zbc1 zcb1; do timeout -k 5 60 tools/bin/timeline_probe 20 512 $k || exit 1; done ) > "$OUT/timeline_probe.txt" 2>&1 || { echo "timeline failed"; exit 1; }
 step "bench sizes" 600 python tools/bench_sizes.py > "$OUT/bench_size_table.txt" 2>&1
