@@ -40,7 +40,7 @@ def main():
                     t0 = time.perf_counter()
                     res[prec] = hwmc.cv_price(e.simulate_ZBC_control_variate(n, a.seed), 2 * n, float(P[-1]))
                     res[prec]["s"] = time.perf_counter() - t0
-            pr = hwmc.default_params(profile, n_steps=grid, precision="f32")
+            pr = hwmc.default_params(profile, n_steps=grid, precision="f32", table_mode="ref_f32")   # the reference's float drift table too (common.cuh:60-84)
             with hwmc.HullWhiteEngine(pr, device=0) as e:
                 e.load_market_data(P, f)
                 ref = hwmc.cv_price(e.simulate_ZBC_control_variate(n, a.seed, stepper=hwmc.HW_STEPPER_REFERENCE), 2 * n, float(P[-1]))
