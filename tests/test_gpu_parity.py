@@ -942,6 +942,20 @@ def test_systematic_distance_to_the_reference_arithmetic_at_scale(hwmc_mod, prof
     print("%s, 2^30 pairs: engine - reference arithmetic %.1e, engine - double %.1e, reference arithmetic - double %.1e of the price"
           % (profile, rel("engine", "reference_arithmetic"), rel("engine", "double"), rel("reference_arithmetic", "double")))
     assert rel("engine", "reference_arithmetic") < 2e-6 and rel("engine", "double") < 2e-6 and rel("reference_arithmetic", "double") < 2e-6, price
+    # the other two kernels, float against double engine on the same draws: pathwise Vega on 2^30 paths (a sum of signed terms:
+    # measured 9e-7 / 4e-7 of the Vega), the curve on 2^28 pairs (every maturity; measured 4e-8)
+    vega, curve = {}, {}
+    for prec in ("f32", "f64"):
+        p = hwmc_mod.default_params(profile, precision=prec)
+        P, f = hwmc_mod.analytic_curve(p)
+        with hwmc_mod.HullWhiteEngine(p, device=0) as e:
+            e.load_market_data(P, f)
+            vega[prec] = e.simulate_sensitivity(n, 99) / n
+            curve[prec] = e.simulate_zcb(1 << 28, 5)
+    assert abs(vega["f32"] - vega["f64"]) < 3e-6 * vega["f64"], vega
+    assert vega["f64"] == pytest.approx(hwmc_mod.closed_form_vega(p, P), abs=8e-5)          # 4 SE at 2^30 paths (sd of one path's integrand 0.58)
+    np.testing.assert_allclose(curve["f32"][1:], curve["f64"][1:], rtol=2e-7)
+    assert curve["f32"][0] == curve["f64"][0] == 2.0 * (1 << 28)
 
 
 def test_weak_mean_reversion_falls_back_to_the_per_step_form(hwmc_mod, oracle_mod):
